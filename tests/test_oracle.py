@@ -1,0 +1,204 @@
+"""Pins oracle/nf_oracle.py to the golden fixtures generated from the reference
+(tests/golden/gen_golden.py).  CPU only.  The oracle issues the same ATen ops as the
+reference, so fp32 results are compared at a few ulp and fp64 results essentially exactly."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_state_dict, rel_err
+from oracle import nf_oracle as O
+
+T = torch.from_numpy
+
+
+@pytest.mark.parametrize('tag', ['K4_T1', 'K8_T3', 'K32_T50'])
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_spline_linear_tails(tag, direction):
+    fx = load_golden('spline_' + tag)
+    K, Tb = int(fx['num_bins']), float(fx['tail_bound'])
+    p = T(fx['params'])
+    x = T(fx[direction + '_x'])
+    inv = direction == 'inv'
+    y, ld, bins = O.rq_spline_linear_tails(x, p[:, :K], p[:, K:2 * K], p[:, 2 * K:], inverse=inv,
+                                           tail_bound=Tb, return_bins=True)
+    assert torch.equal(bins, T(fx[direction + '_bins']).long())          # bit-exact bins
+    assert torch.equal(y, T(fx[direction + '_y32']))                      # same op sequence => same bits
+    assert torch.equal(ld, T(fx[direction + '_ld32']))
+    y64, ld64 = O.rq_spline_linear_tails(x.double(), p[:, :K].double(), p[:, K:2 * K].double(),
+                                         p[:, 2 * K:].double(), inverse=inv, tail_bound=Tb)
+    assert torch.equal(y64, T(fx[direction + '_y64']))
+    assert torch.equal(ld64, T(fx[direction + '_ld64']))
+
+
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_spline_no_tails(direction):
+    fx = load_golden('spline_K8_notails')
+    K = int(fx['num_bins'])
+    p = T(fx['params'])
+    x = T(fx[direction + '_x'])
+    y, ld, bins = O.rq_spline(x, p[:, :K].clone(), p[:, K:2 * K].clone(), p[:, 2 * K:].clone(),
+                              inverse=direction == 'inv', return_bins=True)
+    assert torch.equal(bins, T(fx[direction + '_bins']).long())
+    assert torch.equal(y, T(fx[direction + '_y32']))
+    assert torch.equal(ld, T(fx[direction + '_ld32']))
+
+
+def test_spline_rejects_too_many_bins():
+    with pytest.raises(ValueError):
+        O.rq_spline(torch.zeros(1), torch.zeros(1, 2000), torch.zeros(1, 2000), torch.zeros(1, 2001))
+
+
+def test_tile_and_masks_small():
+    assert O.tile(torch.tensor([1, 2, 3]), 2).tolist() == [1, 1, 2, 2, 3, 3]
+    for tag, kw in [('res', {}), ('ff', dict(use_residual_blocks=False)), ('nb3', dict(num_blocks=3))]:
+        sd = golden_state_dict(load_golden('made_small_' + tag))
+        masks = O.made_masks(6, 16, output_multiplier=23, **kw)
+        assert len(masks) == sum(k.endswith('.mask') for k in sd)
+        for name, (m, deg) in masks.items():
+            assert torch.equal(m, sd[name + '.mask']), name
+            assert torch.equal(deg, sd[name + '.degrees']), name
+
+
+@pytest.mark.parametrize('tag', ['res', 'ff', 'bn', 'ffbn', 'nb3'])
+def test_made_small(tag):
+    fx = load_golden('made_small_' + tag)
+    sd = golden_state_dict(fx)
+    y = O.made_forward(sd, T(fx['x']))
+    assert torch.equal(y, T(fx['y32']))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    assert rel_err(O.made_forward(sd64, T(fx['x']).double()), fx['y64']) < 1e-14
+
+
+def test_made_context():
+    fx = load_golden('made_small_ctx')
+    y = O.made_forward(golden_state_dict(fx), T(fx['x']), context=T(fx['context']))
+    assert torch.equal(y, T(fx['y32']))
+
+
+@pytest.mark.parametrize('tag', ['D64_H128_m23', 'D64_H128_m23_n01', 'D784_H512_m23', 'D784_H512_m2',
+                                 'D5_H32_m23', 'D1_H8_m23'])
+def test_made_seeded(tag):
+    fx = load_golden('made_' + tag)
+    scale = float(fx['scale'])
+    sd = O.seeded_made_state_dict(int(fx['features']), int(fx['hidden']), int(fx['mult']), seed=int(fx['seed']),
+                                  scale=None if scale < 0 else scale, prefix='')
+    for k, v in fx.items():
+        if k.startswith('masksum/'):
+            name = k[len('masksum/'):].replace('/', '.')
+            assert torch.equal(sd[name].sum(1).to(torch.int32), T(v)), name
+    assert torch.equal(O.made_forward(sd, T(fx['x'])), T(fx['y32']))
+
+
+def test_rq_ar_small():
+    fx = load_golden('rqar_small')
+    sd = golden_state_dict(fx)
+    K, Tb = int(fx['num_bins']), float(fx['tail_bound'])
+    L = 3
+    layers = [O.split_state_dict(sd, j) for j in range(L)]
+    x = T(fx['x'])
+    y1, ld1, bins1 = O.rq_autoregressive_forward(layers[0], x, K, Tb, return_bins=True)
+    assert torch.equal(bins1, T(fx['bins1']).long())
+    assert torch.equal(y1, T(fx['y1'])) and torch.equal(ld1, T(fx['ld1']))
+    fwd = [lambda v, s=s: O.rq_autoregressive_forward(s, v, K, Tb) for s in layers]
+    y, ld = O.composite(fwd, x)
+    assert torch.equal(y, T(fx['y'])) and torch.equal(ld, T(fx['ld']))
+    assert rel_err(O.flow_log_prob(fwd, x), fx['logp']) < 1e-6
+    inv = [lambda v, s=s: O.rq_autoregressive_inverse(s, v, K, Tb) for s in reversed(layers)]
+    xs, lds = O.composite(inv, T(fx['z']))
+    assert torch.equal(xs, T(fx['xs'])) and torch.equal(lds, T(fx['lds']))
+    # reference property: inverse(forward(x)) == x, logdets cancel
+    xi, ldi = O.composite(inv, y)
+    assert torch.equal(xi, T(fx['inv_of_y']))
+    # in fp64 the round trip closes (fp32 is conditioning-limited on this x2-scaled model)
+    l64 = [{k: (v.double() if v.is_floating_point() else v) for k, v in s.items()} for s in layers]
+    f64 = [lambda v, s=s: O.rq_autoregressive_forward(s, v, K, Tb) for s in l64]
+    i64 = [lambda v, s=s: O.rq_autoregressive_inverse(s, v, K, Tb) for s in reversed(l64)]
+    y64, ld64 = O.composite(f64, x.double())
+    assert rel_err(y64, fx['y64']) < 1e-13 and rel_err(ld64, fx['ld64']) < 1e-13
+    x64, ldi64 = O.composite(i64, y64)
+    assert rel_err(x64, x.double()) < 1e-4 and (ldi64 + ld64).abs().max() < 1e-4   # error grows per dimension
+
+
+def test_rq_ar_cfg3_forward():
+    fx = load_golden('rqar_cfg3')
+    K, Tb, D, H = int(fx['num_bins']), float(fx['tail_bound']), int(fx['features']), int(fx['hidden'])
+    layers = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=int(s)) for s in fx['seeds']]
+    x = T(fx['x'])
+    y1, ld1, bins1 = O.rq_autoregressive_forward(layers[0], x, K, Tb, return_bins=True)
+    assert torch.equal(bins1, T(fx['bins1']).long())
+    assert torch.equal(y1, T(fx['y1']))
+    fwd = [lambda v, s=s: O.rq_autoregressive_forward(s, v, K, Tb) for s in layers]
+    y, ld = O.composite(fwd, x)
+    assert torch.equal(y, T(fx['y'])) and torch.equal(ld, T(fx['ld']))
+    # the reference's own fp32-vs-fp64 noise floor for this stack
+    assert rel_err(fx['logp'], fx['logp64']) < 5e-6
+
+
+def test_rq_ar_cfg3_inverse_one_row():
+    """784 sequential passes; one sample keeps the CPU suite short."""
+    fx = load_golden('rqar_cfg3')
+    K, Tb, D, H = int(fx['num_bins']), float(fx['tail_bound']), int(fx['features']), int(fx['hidden'])
+    sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=int(fx['seeds'][0]))
+    xs, lds = O.rq_autoregressive_inverse(sd, T(fx['zi'])[:1], K, Tb)
+    # batch-1 GEMMs take a different BLAS path than the fixture's batch-4 run: compare to tolerance
+    assert rel_err(xs, fx['xs1'][:1]) < 1e-4
+    assert rel_err(lds, fx['lds1'][:1], floor=10.) < 1e-5
+
+
+def test_affine_ar():
+    fx = load_golden('affine_ar')
+    sd = golden_state_dict(fx)
+    y, ld = O.affine_autoregressive_forward(sd, T(fx['x']))
+    assert torch.equal(y, T(fx['y'])) and torch.equal(ld, T(fx['ld']))
+    xs, lds = O.affine_autoregressive_inverse(sd, T(fx['z']))
+    assert torch.equal(xs, T(fx['xs'])) and torch.equal(lds, T(fx['lds']))
+
+
+@pytest.mark.parametrize('tag', ['linear', 'notails'])
+def test_rq_coupling(tag):
+    fx = load_golden('rq_coupling_' + tag)
+    sd = golden_state_dict(fx)
+    K, Tb, Hn, L = int(fx['num_bins']), float(fx['tail_bound']), int(fx['hidden']), int(fx['n_layers'])
+    tails = 'linear' if tag == 'linear' else None
+    layers = [O.split_state_dict(sd, j) for j in range(L)]
+    fwd = [lambda v, s=s: O.rq_coupling(s, v, K, tails, Tb, Hn) for s in layers]
+    y, ld = O.composite(fwd, T(fx['x']))
+    assert torch.equal(y, T(fx['y'])) and torch.equal(ld, T(fx['ld']))
+    inv = [lambda v, s=s: O.rq_coupling(s, v, K, tails, Tb, Hn, inverse=True) for s in reversed(layers)]
+    xi, ldi = O.composite(inv, y)
+    assert torch.equal(xi, T(fx['inv_of_y'])) and torch.equal(ldi, T(fx['inv_of_y_ld']))
+
+
+def test_affine_coupling():
+    fx = load_golden('affine_coupling')
+    sd = golden_state_dict(fx)
+    layers = [O.split_state_dict(sd, j) for j in range(int(fx['n_layers']))]
+    y, ld = O.composite([lambda v, s=s: O.affine_coupling(s, v) for s in layers], T(fx['x']))
+    assert torch.equal(y, T(fx['y'])) and torch.equal(ld, T(fx['ld']))
+    xi, ldi = O.composite([lambda v, s=s: O.affine_coupling(s, v, inverse=True) for s in reversed(layers)], y)
+    assert torch.equal(xi, T(fx['inv_of_y'])) and torch.equal(ldi, T(fx['inv_of_y_ld']))
+
+
+@pytest.mark.parametrize('D', [2, 5])
+def test_maf(D):
+    fx = load_golden('maf_D%d' % D)
+    L = int(fx['n_layers'])
+
+    def layer(j):
+        n = sum(1 for k in fx if k.startswith('l%d/w' % j))
+        return ([T(fx['l%d/w%d' % (j, i)]) for i in range(n)], [T(fx['l%d/b%d' % (j, i)]) for i in range(n)],
+                [T(fx['l%d/m%d' % (j, i)]) for i in range(n)], bool(fx['l%d/reverse_input' % j]))
+
+    h = T(fx['z'])
+    tot = torch.zeros(h.shape[0], dtype=torch.float64)
+    for j in range(L):
+        w, b, m, rev = layer(j)
+        h, lj = O.maf_forward(w, b, m, h, rev)
+        assert torch.equal(h, T(fx['l%d/fwd_x' % j])) and torch.equal(lj, T(fx['l%d/fwd_logJ' % j]))
+        tot = tot + lj
+    assert torch.equal(tot, T(fx['logJ']))
+    r = h
+    for j in reversed(range(L)):
+        w, b, m, rev = layer(j)
+        r, lj = O.maf_reverse(w, b, m, r, rev)
+        assert rel_err(r, fx['l%d/rev_z' % j]) < 1e-13 and rel_err(lj, fx['l%d/rev_logJ' % j]) < 1e-13
