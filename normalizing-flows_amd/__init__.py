@@ -1,0 +1,12 @@
+"""MI355X-native flow-transform hot path (MADE conditioner -> affine / RQ-spline transform ->
+per-sample log|det J|) behind the reference's module API.  See DESIGN.md."""
+from . import _lib
+from .made import MADE, MaskedLinear, DenseLinear, MaskedResidualBlock, MaskedFeedforwardBlock, \
+    set_matmul_dtype, get_matmul_dtype
+from .resnet import ResidualNet, ResidualBlock
+from .transforms import CompositeTransform, AutoregressiveTransform, MaskedAffineAutoregressiveTransform, \
+    MaskedPiecewiseRationalQuadraticAutoregressiveTransform, CouplingTransform, AffineCouplingTransform, \
+    PiecewiseRationalQuadraticCouplingTransform
+from .distributions import Distribution, StandardNormal, BaseNeuralSplineFlow, Flow
+
+__all__ = [n for n in dir() if not n.startswith('_')]

@@ -1,0 +1,183 @@
+"""ctypes binding of libnf_hip.so (C ABI: include/nf_hip.h).
+
+The product path has no CPU or PyTorch fallback: if the library is missing, or a tensor is not a
+contiguous-row fp32 tensor on an MI355X, the call raises.  PyTorch is used for device memory,
+streams and torch.distributed only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnf_hip.so')
+
+NF_DTYPE_F32 = 0
+NF_DTYPE_BF16 = 1
+NF_AFFINE_INTERLEAVED = 0
+NF_AFFINE_BLOCKED = 1
+NF_ERR_BINS = -4
+
+_lib = None
+
+_c = ctypes
+_SIGNATURES = {
+    'nf_version': (_c.c_int, []),
+    'nf_strerror': (_c.c_char_p, [_c.c_int]),
+    'nf_made_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    'nf_made_ktab_len': (_c.c_int, [_c.c_int]),
+    'nf_made_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+                                _c.c_void_p, _c.c_void_p]),
+    'nf_masked_linear_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                        _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                        _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                        _c.c_int, _c.c_void_p]),
+    'nf_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_double,
+                              _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64,
+                              _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
+                              _c.c_double, _c.c_int, _c.c_void_p]),
+    'nf_affine_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
+                                 _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_int,
+                                 _c.c_int, _c.c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def load():
+    """Load libnf_hip.so (after torch, so both share one HIP runtime).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libnf_hip.so not found at %s: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(or `make -C normalizing-flows_amd/csrc`).  There is no fallback path.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class NfError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = load().nf_strerror(code).decode()
+        super().__init__('%s failed: %s (code %d)' % (where, msg, code))
+
+
+def _check(code, where):
+    if code != 0:
+        if code == NF_ERR_BINS:
+            # same exception type and wording as the reference (rational_quadratic.py:66-69)
+            raise ValueError('Minimal bin width/height too large for the number of bins')
+        raise NfError(code, where)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a tensor on the GPU (MI355X); this package has no CPU path' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    return t
+
+
+def _rows(t, name):
+    """2-D tensor with unit inner stride -> (ptr, row stride in elements)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError('%s must be 2-D with contiguous rows' % name)
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+class PackedLinear:
+    """Device buffers produced by nf_made_pack for one [out,in] layer."""
+    __slots__ = ('out', 'inp', 'dtype', 'packed', 'ktab', 'bias')
+
+    def __init__(self, weight, mask, bias, dtype=NF_DTYPE_F32):
+        lib = load()
+        w = _dev(weight.detach().contiguous(), 'weight')
+        m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
+        self.out, self.inp = int(w.shape[0]), int(w.shape[1])
+        self.dtype = dtype
+        nbytes = lib.nf_made_packed_bytes(self.out, self.inp, dtype)
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        self.ktab = torch.empty(lib.nf_made_ktab_len(self.out), dtype=torch.int32, device=w.device)
+        self.bias = None if bias is None else _dev(bias.detach().contiguous(), 'bias')
+        with torch.cuda.device(w.device):
+            _check(lib.nf_made_pack(w.data_ptr(), _ptr(m), self.out, self.inp, dtype, self.packed.data_ptr(),
+                                    self.ktab.data_ptr(), _stream()), 'nf_made_pack')
+
+
+def masked_linear(x, pl, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False, out=None):
+    lib = load()
+    _dev(x, 'x')
+    xp, xs = _rows(x, 'x')
+    B = x.shape[0]
+    if x.shape[1] != pl.inp:
+        raise ValueError('Expected %d input features, got %d' % (pl.inp, x.shape[1]))
+    if out is None:
+        out = torch.empty((B, pl.out), dtype=torch.float32, device=x.device)
+    yp, ys = _rows(out, 'out')
+    rp, rs = (None, 0) if residual is None else _rows(_dev(residual, 'residual'), 'residual')
+    with torch.cuda.device(x.device):
+        _check(lib.nf_masked_linear_fwd(xp, xs, pl.packed.data_ptr(), pl.ktab.data_ptr(), _ptr(pl.bias), rp, rs,
+                                        _ptr(in_scale), _ptr(in_shift), yp, ys, B, pl.inp, pl.out,
+                                        int(relu_in), int(relu_out), pl.dtype, _stream()), 'nf_masked_linear_fwd')
+    return out
+
+
+def rqs(x, params, num_bins, tails, tail_bound, inverse=False, pre_div=1.0, feat_index=None, out=None,
+        logabsdet=None, accumulate=False, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3,
+        want_bins=False, num_features=None):
+    """x [B, >=D] rows, params [B, D*P] -> (y, logabsdet[B], bins or None)."""
+    lib = load()
+    _dev(x, 'inputs')
+    _dev(params, 'params')
+    B = x.shape[0]
+    D = int(num_features if num_features is not None else x.shape[1])
+    xp, xs = _rows(x, 'inputs')
+    pp, ps = _rows(params, 'params')
+    if out is None:
+        out = torch.empty_like(x)
+    yp, ys = _rows(out, 'outputs')
+    if logabsdet is None:
+        logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        accumulate = False
+    bins = torch.empty((B, D), dtype=torch.int32, device=x.device) if want_bins else None
+    with torch.cuda.device(x.device):
+        _check(lib.nf_rqs_fwd(xp, xs, _ptr(feat_index), pp, ps, float(pre_div), yp, ys, logabsdet.data_ptr(),
+                              int(accumulate), _ptr(bins), B, D, int(num_bins), 1 if tails == 'linear' else 0,
+                              float(tail_bound), float(min_bin_width), float(min_bin_height),
+                              float(min_derivative), int(inverse), _stream()), 'nf_rqs_fwd')
+    return out, logabsdet, bins
+
+
+def affine(x, params, layout, inverse=False, feat_index=None, out=None, logabsdet=None, accumulate=False,
+           num_features=None):
+    lib = load()
+    _dev(x, 'inputs')
+    _dev(params, 'params')
+    B = x.shape[0]
+    D = int(num_features if num_features is not None else x.shape[1])
+    xp, xs = _rows(x, 'inputs')
+    pp, ps = _rows(params, 'params')
+    if out is None:
+        out = torch.empty_like(x)
+    yp, ys = _rows(out, 'outputs')
+    if logabsdet is None:
+        logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        accumulate = False
+    with torch.cuda.device(x.device):
+        _check(lib.nf_affine_fwd(xp, xs, _ptr(feat_index), pp, ps, int(layout), yp, ys, logabsdet.data_ptr(),
+                                 int(accumulate), B, D, int(inverse), _stream()), 'nf_affine_fwd')
+    return out, logabsdet

@@ -1,0 +1,26 @@
+// Shared declarations for the gfx950 kernels behind include/nf_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Return codes of the C-ABI: 0 ok, negative = argument error (below), positive = hipError_t.
+#define NF_OK 0
+#define NF_ERR_NULL (-1)        // a required pointer is null
+#define NF_ERR_SHAPE (-2)       // sizes inconsistent or out of the supported range
+#define NF_ERR_LAYOUT (-3)      // stride / alignment the kernels do not accept
+#define NF_ERR_BINS (-4)        // min_bin_width/height * num_bins > 1 (reference raises ValueError)
+#define NF_ERR_DTYPE (-5)       // unknown dtype / layout enum
+#define NF_ERR_SCRATCH (-6)     // workspace too small
+
+#define NF_DTYPE_F32 0
+#define NF_DTYPE_BF16 1
+
+#define NF_AFFINE_INTERLEAVED 0  // params[b, 2d] = unconstrained scale, [2d+1] = shift (autoregressive)
+#define NF_AFFINE_BLOCKED 1      // params[b, d] = shift, params[b, D+d] = unconstrained scale (coupling)
+
+static inline int nf_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? NF_OK : (int)e;
+}
+
+static inline int nf_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,283 @@
+// MADE masked-linear layers on the gfx950 matrix cores.
+//   y[B,out] = act_out( act_in(x * in_scale + in_shift)[B,in] @ (W*mask)^T + bias (+ residual) )
+// Reference: models/made.py:150-152 (F.linear(x, W*mask, b) with the mask re-multiplied on every
+// call), :196-207 and :268-284 (the ReLU / BatchNorm / skip around it).
+//
+// Here the mask is folded into the weights ONCE (nf_made_pack): the packed matrix is zero-padded
+// to 128-row x 32-column tiles, and a per-row-tile table records which 32-wide K tiles hold any
+// unmasked weight, so the GEMM never loads or multiplies a fully masked tile (the autoregressive
+// masks are triangular: SURVEY.md 2.3).
+//
+// f32 path: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).  Block tile 128x128x32,
+// 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator registers).  Operands are
+// staged global -> registers -> LDS (rows padded to 36 floats: conflict-free ds_read_b128), the next
+// K tile's global loads are issued before the current tile's 64 MFMAs.  A lane reads 4 consecutive
+// k per ds_read_b128; within an 8-wide K chunk lanes 0-31 own k 0..3 and lanes 32-63 own k 4..7, for
+// A and B alike, which is a reordering of the K sum the instruction is indifferent to.
+#include "nf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_LD = BK + 4;          // padded row, floats
+constexpr int GT = 256;                 // threads
+constexpr int GROUP_M = 8;              // row tiles that share a weight tile back to back (L2 reuse)
+
+struct GemmArgs {
+    const float* x;
+    int64_t ldx;
+    const float* w;          // packed [n_tiles*128][kpad]
+    int kpad;
+    const int32_t* ktab;     // [n_tiles][2] = first / one-past-last K tile with unmasked weights
+    const float* bias;       // nullable
+    const float* res;        // nullable
+    int64_t ldr;
+    const float* in_scale;   // nullable (eval-mode BatchNorm folded to scale/shift on the input)
+    const float* in_shift;
+    float* y;
+    int64_t ldy;
+    int64_t M;
+    int N, K;
+    int relu_in, relu_out;
+    int n_tiles;
+    int64_t m_tiles;
+    int vec_a;               // x rows 16-byte aligned and K % 4 == 0
+};
+
+__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int64_t& tm, int& tn) {
+    // XCD-aware order: blocks that share an XCD (id % 8) get one contiguous run of work items; inside
+    // the run GROUP_M row tiles sweep a weight tile together, so the 4 MiB L2 of that XCD sees each
+    // operand panel a handful of times instead of once per block.
+    const int64_t nwg = (int64_t)gridDim.x;
+    const int64_t bid = blockIdx.x;
+    const int64_t q = nwg / 8, r = nwg % 8;
+    const int64_t xcd = bid % 8;
+    const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    const int64_t per_group = (int64_t)GROUP_M * g.n_tiles;
+    const int64_t grp = wg / per_group;
+    const int64_t first_m = grp * GROUP_M;
+    const int64_t gm = min((int64_t)GROUP_M, g.m_tiles - first_m);
+    const int64_t in = wg - grp * per_group;
+    tm = first_m + in % gm;
+    tn = (int)(in / gm);
+}
+
+__global__ __launch_bounds__(GT) void masked_linear_f32_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+
+    int64_t tm;
+    int tn;
+    tile_of_block(g, tm, tn);
+    const int64_t m0 = tm * BM;
+    const int n0 = tn * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int kt_begin = g.ktab[2 * tn], kt_end = g.ktab[2 * tn + 1];
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // staging map: float4 index v = tid + 256*i -> row v>>3, k-offset 4*(v&7)
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = tid + GT * i;
+            const int row = v >> 3, kc = (v & 7) * 4;
+            const int64_t m = m0 + row;
+            const int k = k0 + kc;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < g.M) {
+                const float* src = g.x + m * g.ldx + k;
+                if (g.vec_a) {
+                    if (k < g.K) a = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (k < g.K) a.x = src[0];
+                    if (k + 1 < g.K) a.y = src[1];
+                    if (k + 2 < g.K) a.z = src[2];
+                    if (k + 3 < g.K) a.w = src[3];
+                }
+                if (g.in_scale) {
+                    // K % 4 != 0 tails: scale/shift beyond K multiply zeros; guard the loads
+                    float sc[4], sh[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = k + j < g.K;
+                        sc[j] = ok ? g.in_scale[k + j] : 0.f;
+                        sh[j] = ok ? g.in_shift[k + j] : 0.f;
+                    }
+                    a.x = a.x * sc[0] + sh[0];
+                    a.y = a.y * sc[1] + sh[1];
+                    a.z = a.z * sc[2] + sh[2];
+                    a.w = a.w * sc[3] + sh[3];
+                }
+                if (g.relu_in) {
+                    a.x = fmaxf(a.x, 0.f);
+                    a.y = fmaxf(a.y, 0.f);
+                    a.z = fmaxf(a.z, 0.f);
+                    a.w = fmaxf(a.w, 0.f);
+                }
+            }
+            ra[i] = a;
+            rb[i] = *reinterpret_cast<const float4*>(g.w + (int64_t)(n0 + row) * g.kpad + k);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = tid + GT * i;
+            const int row = v >> 3, kc = (v & 7) * 4;
+            *reinterpret_cast<float4*>(&As[row * LDS_LD + kc]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[row * LDS_LD + kc]) = rb[i];
+        }
+    };
+
+    if (kt_begin < kt_end) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();             // everyone done reading the previous tile
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);      // in flight under the MFMAs below
+
+        const int frow = lane & 31, fk = (lane >> 5) * 4;
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4*>(&As[(wr * 64 + i * 32 + frow) * LDS_LD + kc * 8 + fk]);
+                b[i] = *reinterpret_cast<const float4*>(&Bs[(wc * 64 + i * 32 + frow) * LDS_LD + kc * 8 + fk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (g.res) v += g.res[row * g.ldr + col];
+                if (g.relu_out) v = fmaxf(v, 0.0f);
+                g.y[row * g.ldy + col] = v;
+            }
+        }
+}
+
+// ---- packing ---------------------------------------------------------------------------------
+__global__ void pack_f32_kernel(const float* __restrict__ W, const float* __restrict__ mask, int out, int in,
+                                int kpad, int64_t total, float* __restrict__ packed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / kpad;
+        const int k = (int)(i - n * kpad);
+        float v = 0.0f;
+        if (n < out && k < in) {
+            v = W[n * in + k];
+            if (mask) v *= mask[n * in + k];
+        }
+        packed[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void ktab_kernel(const float* __restrict__ mask, int out, int in, int kpad,
+                                                   int32_t* __restrict__ ktab) {
+    __shared__ int lo, hi;
+    const int tn = blockIdx.x;
+    if (threadIdx.x == 0) { lo = 0x7fffffff; hi = -1; }
+    __syncthreads();
+    int mylo = 0x7fffffff, myhi = -1;
+    if (mask) {
+        const int rows = min(BN, out - tn * BN);
+        for (int64_t i = threadIdx.x; i < (int64_t)rows * in; i += blockDim.x) {
+            const int r = (int)(i / in), k = (int)(i - (int64_t)r * in);
+            if (mask[(int64_t)(tn * BN + r) * in + k] != 0.0f) { mylo = min(mylo, k); myhi = max(myhi, k); }
+        }
+    } else {
+        mylo = 0;
+        myhi = in - 1;
+    }
+    atomicMin(&lo, mylo);
+    atomicMax(&hi, myhi);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (hi < 0) { ktab[2 * tn] = 0; ktab[2 * tn + 1] = 0; }
+        else { ktab[2 * tn] = lo / BK; ktab[2 * tn + 1] = hi / BK + 1; }
+    }
+}
+
+inline int n_tiles_of(int out) { return (out + BN - 1) / BN; }
+inline int kpad_of(int in) { return (in + BK - 1) / BK * BK; }
+
+}  // namespace
+
+extern "C" size_t nf_made_packed_bytes(int out, int in, int dtype) {
+    if (out <= 0 || in <= 0) return 0;
+    const size_t elems = (size_t)n_tiles_of(out) * BN * kpad_of(in);
+    return dtype == NF_DTYPE_BF16 ? elems * 2 : elems * 4;
+}
+
+extern "C" int nf_made_ktab_len(int out) { return out <= 0 ? 0 : 2 * n_tiles_of(out); }
+
+extern "C" int nf_made_pack(const float* W, const float* mask, int out, int in, int dtype, void* packed,
+                            int32_t* ktab, void* stream) {
+    if (!W || !packed || !ktab) return NF_ERR_NULL;
+    if (out <= 0 || in <= 0) return NF_ERR_SHAPE;
+    if (dtype != NF_DTYPE_F32) return NF_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int kpad = kpad_of(in);
+    const int64_t total = (int64_t)n_tiles_of(out) * BN * kpad;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_f32_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, kpad, total, (float*)packed);
+    hipLaunchKernelGGL(ktab_kernel, dim3(n_tiles_of(out)), dim3(256), 0, s, mask, out, in, kpad, ktab);
+    return nf_launch_status();
+}
+
+extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const void* packed_w, const int32_t* ktab,
+                                    const float* bias, const float* residual, int64_t residual_row_stride,
+                                    const float* in_scale, const float* in_shift, float* y, int64_t y_row_stride,
+                                    int64_t B, int in, int out, int relu_in, int relu_out, int dtype, void* stream) {
+    if (!x || !packed_w || !ktab || !y) return NF_ERR_NULL;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return NF_ERR_NULL;
+    if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
+    if (x_row_stride < in || y_row_stride < out || (residual && residual_row_stride < out)) return NF_ERR_LAYOUT;
+    if (dtype != NF_DTYPE_F32) return NF_ERR_DTYPE;
+    if (B == 0) return NF_OK;
+    GemmArgs g;
+    g.x = x; g.ldx = x_row_stride; g.w = (const float*)packed_w; g.kpad = kpad_of(in); g.ktab = ktab;
+    g.bias = bias; g.res = residual; g.ldr = residual_row_stride; g.in_scale = in_scale; g.in_shift = in_shift;
+    g.y = y; g.ldy = y_row_stride; g.M = B; g.N = out; g.K = in; g.relu_in = relu_in; g.relu_out = relu_out;
+    g.n_tiles = n_tiles_of(out);
+    g.m_tiles = (B + BM - 1) / BM;
+    g.vec_a = (in % 4 == 0) && (x_row_stride % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    const int64_t grid = g.m_tiles * g.n_tiles;
+    if (grid > 0x7fffffff) return NF_ERR_SHAPE;
+    hipLaunchKernelGGL(masked_linear_f32_kernel, dim3((int)grid), dim3(GT), 0, (hipStream_t)stream, g);
+    return nf_launch_status();
+}

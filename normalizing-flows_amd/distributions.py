@@ -1,0 +1,120 @@
+"""Density / sampling wrapper around a transform (reference models/distributions.py:7-196 and the
+two data-flow loops of models/model.py:78-108).
+
+    log_prob(x)  = base.log_prob(T(x)) + logabsdet            (distributions.py:154-157)
+    sample(n)    = T^-1(z), z ~ base                           (distributions.py:159-171)
+    forward(z)   = T.inverse(z);  reverse(x) = T(x)            (distributions.py:192-196)
+
+The reference's own `SimpleNormal` cannot be used with its `BaseNeuralSplineFlow.log_prob/sample`
+(wrong keyword / missing method); `StandardNormal` here implements the protocol
+those methods call (`log_prob(x, context=None)`, `sample(n, context=None)`) with the same density.
+"""
+import math
+
+import torch
+from torch import nn
+
+
+def _is_positive_int(x):
+    return isinstance(x, int) and x > 0
+
+
+class Distribution(nn.Module):
+    """Base class (reference distributions.py:7-69)."""
+
+    def forward(self, *args):
+        raise RuntimeError('Forward method cannot be called for a Distribution object.')
+
+    def log_prob(self, inputs, context=None):
+        inputs = torch.as_tensor(inputs)
+        if context is not None:
+            context = torch.as_tensor(context)
+            if inputs.shape[0] != context.shape[0]:
+                raise ValueError('Number of input items must be equal to number of context items.')
+        return self._log_prob(inputs, context)
+
+    def _log_prob(self, inputs, context):
+        raise NotImplementedError()
+
+    def sample(self, num_samples, context=None, batch_size=None):
+        if not _is_positive_int(num_samples):
+            raise TypeError('Number of samples must be a positive integer.')
+        if context is not None:
+            context = torch.as_tensor(context)
+        if batch_size is None:
+            return self._sample(num_samples, context)
+        if not _is_positive_int(batch_size):
+            raise TypeError('Batch size must be a positive integer.')
+        num_batches, num_leftover = divmod(num_samples, batch_size)
+        samples = [self._sample(batch_size, context) for _ in range(num_batches)]
+        if num_leftover > 0:
+            samples.append(self._sample(num_leftover, context))
+        return torch.cat(samples, dim=0)
+
+    def _sample(self, num_samples, context):
+        raise NotImplementedError()
+
+    def sample_and_log_prob(self, num_samples, context=None):
+        samples = self.sample(num_samples, context=context)
+        return samples, self.log_prob(samples, context=context)
+
+
+class StandardNormal(Distribution):
+    """N(0, I) over `shape` features; density as SimpleNormal.log_prob (distributions.py:105-107)."""
+
+    def __init__(self, shape, device=None):
+        super().__init__()
+        self._shape = torch.Size([shape] if isinstance(shape, int) else shape)
+        self.register_buffer('_anchor', torch.zeros(1, device=device))
+        self.generator = None
+
+    def _log_prob(self, inputs, context=None):
+        if inputs.shape[1:] != self._shape:
+            raise ValueError('Expected input of shape {}, got {}'.format(self._shape, inputs.shape[1:]))
+        n = inputs.shape[0]
+        return (-0.5 * inputs.pow(2) - 0.5 * math.log(2 * math.pi)).reshape(n, -1).sum(dim=1)
+
+    def _sample(self, num_samples, context=None):
+        return torch.randn(num_samples, *self._shape, device=self._anchor.device, generator=self.generator)
+
+    # legacy spelling used by models/model.py:78-108
+    def sample_n(self, batch_size):
+        return self._sample(batch_size)
+
+
+class BaseNeuralSplineFlow(Distribution):
+    """A transform plus a base distribution (reference distributions.py:147-196)."""
+
+    def __init__(self, transform, distribution):
+        super().__init__()
+        self._transform = transform
+        self._distribution = distribution
+
+    def _log_prob(self, inputs, context):
+        noise, logabsdet = self._transform(inputs, context=context)
+        return self._distribution.log_prob(noise, context=context) + logabsdet
+
+    def _sample(self, num_samples, context):
+        if context is not None:
+            raise NotImplementedError('conditional sampling is outside this path')
+        noise = self._distribution.sample(num_samples)
+        samples, _ = self._transform.inverse(noise, context=None)
+        return samples
+
+    def sample_and_log_prob(self, num_samples, context=None):
+        noise, log_prob = self._distribution.sample_and_log_prob(num_samples, context=context)
+        samples, logabsdet = self._transform.inverse(noise, context=context)
+        return samples, log_prob - logabsdet
+
+    def transform_to_noise(self, inputs, context=None):
+        noise, _ = self._transform(inputs, context=context)
+        return noise
+
+    def forward(self, z):
+        return self._transform.inverse(z)
+
+    def reverse(self, x):
+        return self._transform(x)
+
+
+Flow = BaseNeuralSplineFlow

@@ -1,0 +1,227 @@
+"""MADE masked-linear conditioner on the MI355X matrix cores.
+
+Drop-in for the reference's models/made.py:91-359 on this path: same constructor arguments, same
+submodule / buffer names (so a reference ``state_dict`` loads with ``strict=True``), same
+``forward(inputs, context=None) -> [B, features*output_multiplier]``.  What differs is the execution:
+``weight * mask`` is folded once into a packed, tile-padded device matrix with a table of unmasked K
+tiles (nf_made_pack) and every layer runs as one fused MFMA kernel (nf_masked_linear_fwd) with the
+ReLU / eval-BatchNorm prologue and the bias / skip epilogue inside it.
+
+Scope of this build: inference (``eval()``; dropout off, BatchNorm running statistics), ReLU
+activation (the reference default).  Anything else raises instead of silently taking another path.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F, init
+
+from . import _lib
+
+_MATMUL_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16}
+_default_matmul = 'f32'
+
+
+def set_matmul_dtype(name):
+    """'f32' (exact fp32 MFMA, the 1e-5 contract) or 'bf16' (bf16 MFMA, the 2e-2 contract)."""
+    global _default_matmul
+    if name not in _MATMUL_DTYPE:
+        raise ValueError('matmul dtype must be one of %s' % sorted(_MATMUL_DTYPE))
+    _default_matmul = name
+
+
+def get_matmul_dtype():
+    return _default_matmul
+
+
+def tile(x, n):
+    """Each element repeated n times in place order (reference helper_functions.py:382-390)."""
+    if not (isinstance(n, int) and n > 0):
+        raise TypeError('Argument \'n\' must be a positive integer.')
+    return x.reshape(-1, 1).repeat(1, n).reshape(-1)
+
+
+def _get_input_degrees(in_features):
+    return torch.arange(1, in_features + 1)
+
+
+def _require_inference(module, activation=None):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters(recurse=False)):
+        raise NotImplementedError(
+            'normalizing-flows_amd runs the HIP inference path only: call under torch.no_grad() '
+            '(backward kernels are not part of this build).')
+
+
+class _PackedMixin:
+    """Caches the packed weights; rebuilt when the parameters change or the MFMA dtype is switched."""
+
+    def _packed_linear(self):
+        mask = getattr(self, 'mask', None)
+        key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
+               get_matmul_dtype(), self.weight.device)
+        cached = getattr(self, '_pack_cache', None)
+        if cached is None or cached[0] != key:
+            pl = _lib.PackedLinear(self.weight, mask, self.bias, _MATMUL_DTYPE[get_matmul_dtype()])
+            object.__setattr__(self, '_pack_cache', (key, pl))
+            cached = self._pack_cache
+        return cached[1]
+
+    def fused(self, x, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False):
+        _require_inference(self)
+        return _lib.masked_linear(x, self._packed_linear(), residual=residual, in_scale=in_scale,
+                                  in_shift=in_shift, relu_in=relu_in, relu_out=relu_out)
+
+
+class DenseLinear(_PackedMixin, nn.Linear):
+    """nn.Linear executed by the same kernel with no mask (context layers, ResidualNet)."""
+
+    def forward(self, x):
+        return self.fused(x)
+
+
+class MaskedLinear(_PackedMixin, nn.Linear):
+    """Linear layer with a fixed autoregressive 0/1 mask (reference made.py:96-152)."""
+
+    def __init__(self, in_degrees, out_features, autoregressive_features, random_mask, is_output, bias=True):
+        super().__init__(in_features=len(in_degrees), out_features=out_features, bias=bias)
+        mask, degrees = self._get_mask_and_degrees(in_degrees, out_features, autoregressive_features,
+                                                   random_mask, is_output)
+        self.register_buffer('mask', mask)
+        self.register_buffer('degrees', degrees)
+
+    @classmethod
+    def _get_mask_and_degrees(cls, in_degrees, out_features, autoregressive_features, random_mask, is_output):
+        in_degrees = in_degrees.cpu()
+        if is_output:
+            # every feature's parameters may see strictly earlier features only
+            out_degrees = tile(_get_input_degrees(autoregressive_features), out_features // autoregressive_features)
+            mask = (out_degrees[..., None] > in_degrees).float()
+        else:
+            if random_mask:
+                low = min(torch.min(in_degrees).item(), autoregressive_features - 1)
+                out_degrees = torch.randint(low=low, high=autoregressive_features, size=[out_features],
+                                            dtype=torch.long)
+            else:
+                hi = max(1, autoregressive_features - 1)
+                lo = min(1, autoregressive_features - 1)
+                out_degrees = torch.arange(out_features) % hi + lo
+            mask = (out_degrees[..., None] >= in_degrees).float()
+        return mask, out_degrees
+
+    def forward(self, x):
+        return self.fused(x)
+
+
+def _bn_scale_shift(bn):
+    """Eval-mode BatchNorm1d as y = x*scale + shift."""
+    if bn.training:
+        raise NotImplementedError('BatchNorm in train() mode couples samples across the batch; call eval().')
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias - bn.running_mean * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def _check_activation(activation):
+    if activation is not F.relu and activation is not torch.relu:
+        raise NotImplementedError('only the reference default activation (F.relu) is fused into the kernels')
+
+
+class MaskedFeedforwardBlock(nn.Module):
+    """BN? -> masked linear -> relu -> dropout (reference made.py:155-207)."""
+
+    def __init__(self, in_degrees, autoregressive_features, context_features=None, random_mask=False,
+                 activation=F.relu, dropout_probability=0., use_batch_norm=False):
+        super().__init__()
+        features = len(in_degrees)
+        self.batch_norm = nn.BatchNorm1d(features, eps=1e-3) if use_batch_norm else None
+        if context_features is not None:
+            raise NotImplementedError()
+        self.linear = MaskedLinear(in_degrees, features, autoregressive_features, random_mask, is_output=False)
+        self.degrees = self.linear.degrees
+        _check_activation(activation)
+        self.activation = activation
+        self.dropout = nn.Dropout(p=dropout_probability)
+
+    def forward(self, inputs, context=None):
+        if context is not None:
+            raise NotImplementedError()
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError('dropout needs train(); this build is inference only')
+        sc, sh = _bn_scale_shift(self.batch_norm) if self.batch_norm is not None else (None, None)
+        return self.linear.fused(inputs, in_scale=sc, in_shift=sh, relu_out=True)
+
+
+class MaskedResidualBlock(nn.Module):
+    """x + ML1(relu(BN1?(ML0(relu(BN0?(x)))))) (reference made.py:210-284)."""
+
+    def __init__(self, in_degrees, autoregressive_features, context_features=None, random_mask=False,
+                 activation=F.relu, dropout_probability=0., use_batch_norm=False, zero_initialization=True):
+        if random_mask:
+            raise ValueError('Masked residual block can\'t be used with random masks.')
+        super().__init__()
+        features = len(in_degrees)
+        if context_features is not None:
+            self.context_layer = DenseLinear(context_features, features)
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList([nn.BatchNorm1d(features, eps=1e-3) for _ in range(2)])
+        linear_0 = MaskedLinear(in_degrees, features, autoregressive_features, False, is_output=False)
+        linear_1 = MaskedLinear(linear_0.degrees, features, autoregressive_features, False, is_output=False)
+        self.linear_layers = nn.ModuleList([linear_0, linear_1])
+        self.degrees = linear_1.degrees
+        if torch.all(self.degrees >= in_degrees.cpu()).item() != 1:
+            raise RuntimeError('In a masked residual block, the output degrees can\'t be'
+                               ' less than the corresponding input degrees.')
+        _check_activation(activation)
+        self.activation = activation
+        self.dropout = nn.Dropout(p=dropout_probability)
+        if zero_initialization:
+            init.uniform_(self.linear_layers[-1].weight, a=-1e-3, b=1e-3)
+            init.uniform_(self.linear_layers[-1].bias, a=-1e-3, b=1e-3)
+
+    def forward(self, inputs, context=None):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError('dropout needs train(); this build is inference only')
+        s0 = h0 = s1 = h1 = None
+        if self.use_batch_norm:
+            s0, h0 = _bn_scale_shift(self.batch_norm_layers[0])
+            s1, h1 = _bn_scale_shift(self.batch_norm_layers[1])
+        temps = self.linear_layers[0].fused(inputs, in_scale=s0, in_shift=h0, relu_in=True)
+        if context is None:
+            return self.linear_layers[1].fused(temps, in_scale=s1, in_shift=h1, relu_in=True, residual=inputs)
+        temps = self.linear_layers[1].fused(temps, in_scale=s1, in_shift=h1, relu_in=True)
+        # GLU gate from the context (made.py:279-283): elementwise glue around the fused layers
+        return inputs + temps * torch.sigmoid(self.context_layer(context))
+
+
+class MADE(nn.Module):
+    """Masked autoregressive conditioner (reference made.py:287-359)."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_blocks=2, output_multiplier=1,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu, dropout_probability=0.,
+                 use_batch_norm=False):
+        if use_residual_blocks and random_mask:
+            raise ValueError('Residual blocks can\'t be used with random masks.')
+        super().__init__()
+        self.initial_layer = MaskedLinear(_get_input_degrees(features), hidden_features, features, random_mask,
+                                          is_output=False)
+        if context_features is not None:
+            self.context_layer = DenseLinear(context_features, hidden_features)
+        block = MaskedResidualBlock if use_residual_blocks else MaskedFeedforwardBlock
+        prev = self.initial_layer.degrees
+        blocks = []
+        for _ in range(num_blocks):
+            blocks.append(block(in_degrees=prev, autoregressive_features=features,
+                                context_features=context_features, random_mask=random_mask,
+                                activation=activation, dropout_probability=dropout_probability,
+                                use_batch_norm=use_batch_norm))
+            prev = blocks[-1].degrees
+        self.blocks = nn.ModuleList(blocks)
+        self.final_layer = MaskedLinear(prev, features * output_multiplier, features, random_mask, is_output=True)
+
+    def forward(self, inputs, context=None):
+        if context is None:
+            outputs = self.initial_layer.fused(inputs)
+        else:
+            outputs = self.initial_layer.fused(inputs, residual=self.context_layer(context))
+        for block in self.blocks:
+            outputs = block(outputs, context)
+        return self.final_layer.fused(outputs)

@@ -1,0 +1,69 @@
+"""Dense residual MLP: the coupling-layer conditioner (reference models/nn/resnet.py:9-100).
+
+Same constructor, submodule names and `hidden_features` attribute as the reference; each layer is
+the fused MFMA kernel of ``made.py`` with no mask (ReLU / eval-BatchNorm prologue, bias + skip
+epilogue inside the kernel).
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F, init
+
+from .made import DenseLinear, _bn_scale_shift, _check_activation
+
+
+class ResidualBlock(nn.Module):
+    """x + L1(relu(BN1?(L0(relu(BN0?(x)))))) (reference resnet.py:9-57)."""
+
+    def __init__(self, features, context_features, activation=F.relu, dropout_probability=0.,
+                 use_batch_norm=False, zero_initialization=True):
+        super().__init__()
+        _check_activation(activation)
+        self.activation = activation
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList([nn.BatchNorm1d(features, eps=1e-3) for _ in range(2)])
+        if context_features is not None:
+            self.context_layer = DenseLinear(context_features, features)
+        self.linear_layers = nn.ModuleList([DenseLinear(features, features) for _ in range(2)])
+        self.dropout = nn.Dropout(p=dropout_probability)
+        if zero_initialization:
+            init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)
+            init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
+
+    def forward(self, inputs, context=None):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError('dropout needs train(); this build is inference only')
+        s0 = h0 = s1 = h1 = None
+        if self.use_batch_norm:
+            s0, h0 = _bn_scale_shift(self.batch_norm_layers[0])
+            s1, h1 = _bn_scale_shift(self.batch_norm_layers[1])
+        temps = self.linear_layers[0].fused(inputs, in_scale=s0, in_shift=h0, relu_in=True)
+        if context is None:
+            return self.linear_layers[1].fused(temps, in_scale=s1, in_shift=h1, relu_in=True, residual=inputs)
+        temps = self.linear_layers[1].fused(temps, in_scale=s1, in_shift=h1, relu_in=True)
+        return inputs + temps * torch.sigmoid(self.context_layer(context))
+
+
+class ResidualNet(nn.Module):
+    """initial linear -> residual blocks -> final linear (reference resnet.py:60-100)."""
+
+    def __init__(self, in_features, out_features, hidden_features, context_features=None, num_blocks=2,
+                 activation=F.relu, dropout_probability=0., use_batch_norm=False):
+        super().__init__()
+        self.hidden_features = hidden_features
+        self.context_features = context_features
+        first_in = in_features if context_features is None else in_features + context_features
+        self.initial_layer = DenseLinear(first_in, hidden_features)
+        self.blocks = nn.ModuleList([
+            ResidualBlock(features=hidden_features, context_features=context_features, activation=activation,
+                          dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
+            for _ in range(num_blocks)])
+        self.final_layer = DenseLinear(hidden_features, out_features)
+
+    def forward(self, inputs, context=None):
+        if context is not None:
+            inputs = torch.cat((inputs, context), dim=1)
+        temps = self.initial_layer(inputs)
+        for block in self.blocks:
+            temps = block(temps, context=context)
+        return self.final_layer(temps)

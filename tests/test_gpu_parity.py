@@ -1,0 +1,351 @@
+"""Parity of the HIP path (through the C ABI, via the drop-in modules) with the reference.
+
+Every test runs on a real MI355X (`-m gpu`).  Expected values are (a) the golden fixtures written
+from the reference itself (tests/golden/gen_golden.py) and (b) oracle/nf_oracle.py on seeded inputs.
+
+Tolerances (BASELINE.json north_star): spline bin indices bit-exact; outputs / logabsdet /
+log_prob within 1e-5 relative in fp32 mode, measured as max|a-b| / max(1,|b|) against the
+reference's float64 result; 2e-2 for the bf16-MFMA mode.  Where the reference's own fp32 result is
+further than that from its fp64 result (the D-pass inverse: BASELINE.md sec. 2) the bound is a small
+multiple of that noise floor instead, stated in the test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_state_dict, rel_err
+from oracle import nf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def nf():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import normalizing_flows_amd as nf
+    nf._lib.load()
+    nf.set_matmul_dtype('f32')
+    return nf
+
+
+def dev(a):
+    return (T(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a).cuda()
+
+
+def assert_close(got, ref64, ref32=None, tol=TOL, mult=4.0):
+    """|got - ref64| / max(1,|ref64|) <= tol on 99% of the elements, and everywhere <= max(tol,
+    mult x the reference's own fp32-vs-fp64 distance) - a handful of ill-conditioned elements (tiny
+    bins, cancelling logs) sit above 1e-5 in the reference's own fp32 run."""
+    got = torch.as_tensor(got).double().cpu().reshape(-1)
+    ref64 = torch.as_tensor(ref64).double().reshape(-1)
+    e = (got - ref64).abs() / ref64.abs().clamp_min(1.0)
+    floor = 0.0 if ref32 is None else rel_err(torch.as_tensor(ref32).reshape(-1), ref64)
+    assert e.max().item() <= max(tol, mult * floor), (e.max().item(), floor)
+    if e.numel() >= 100:
+        assert torch.quantile(e, 0.99).item() <= tol, torch.quantile(e, 0.99).item()
+
+
+def check_bins(bins_hip, bins_ref, x, knots, tol):
+    """Bit-exact, except where x sits within `tol` of the knot separating the two answers (there the
+    reference's own fp32 and fp64 runs may disagree too).  Returns the number of such flips."""
+    bins_hip = bins_hip.cpu().long()
+    bins_ref = bins_ref.long()
+    diff = bins_hip != bins_ref
+    n = int(diff.sum())
+    if n:
+        assert ((bins_hip - bins_ref).abs()[diff] == 1).all(), 'bin index off by more than one'
+        edge = torch.maximum(bins_hip, bins_ref)[diff]
+        k = knots[diff].gather(-1, edge[:, None])[:, 0]
+        assert ((x[diff].double() - k).abs() <= tol).all(), 'bin flip away from a knot'
+    return n
+
+
+# ------------------------------------------------------------------------------- spline alone
+@pytest.mark.parametrize('tag', ['K4_T1', 'K8_T3', 'K32_T50'])
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_rqs_linear_tails_golden(nf, tag, direction):
+    fx = load_golden('spline_' + tag)
+    K, Tb = int(fx['num_bins']), float(fx['tail_bound'])
+    N = fx['params'].shape[0]
+    D = 16
+    x = dev(fx[direction + '_x']).reshape(N // D, D)
+    params = dev(fx['params']).reshape(N // D, -1)
+    y, lad, bins = nf._lib.rqs(x, params, K, 'linear', Tb, inverse=direction == 'inv', want_bins=True)
+    assert torch.equal(bins.cpu().reshape(-1).long(), T(fx[direction + '_bins']).long())     # bit-exact
+    assert_close(y, fx[direction + '_y64'], fx[direction + '_y32'])
+    ld64 = T(fx[direction + '_ld64']).reshape(N // D, D).sum(1)
+    assert_close(lad, ld64, T(fx[direction + '_ld32']).reshape(N // D, D).sum(1))
+    # tails: identity and zero logdet, exactly
+    outside = np.abs(fx[direction + '_x']) > Tb
+    assert np.array_equal(y.cpu().reshape(-1).numpy()[outside], fx[direction + '_x'][outside])
+
+
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_rqs_no_tails_golden(nf, direction):
+    fx = load_golden('spline_K8_notails')
+    K = int(fx['num_bins'])
+    N = fx['params'].shape[0]
+    x = dev(fx[direction + '_x']).reshape(N // 8, 8)
+    params = dev(fx['params']).reshape(N // 8, -1)
+    y, lad, bins = nf._lib.rqs(x, params, K, None, 1.0, inverse=direction == 'inv', want_bins=True)
+    assert torch.equal(bins.cpu().reshape(-1).long(), T(fx[direction + '_bins']).long())
+    assert_close(y, fx[direction + '_y64'], fx[direction + '_y32'])
+    assert_close(lad, T(fx[direction + '_ld64']).reshape(N // 8, 8).sum(1),
+                 T(fx[direction + '_ld32']).reshape(N // 8, 8).sum(1))
+
+
+@pytest.mark.parametrize('B,D,K', [(1, 1, 8), (3, 5, 4), (7, 784, 8), (129, 33, 10), (5, 3, 7), (2, 4000, 8)])
+def test_rqs_ragged_shapes_vs_oracle(nf, B, D, K):
+    g = torch.Generator().manual_seed(B * 1000 + D)
+    P = 3 * K - 1
+    x = torch.randn(B, D, generator=g) * 2.0
+    params = torch.randn(B, D * P, generator=g)
+    tp = params.view(B, D, P).double()
+    for inverse in (False, True):
+        yo, ldo, bo = O.rq_spline_linear_tails(x.double(), tp[..., :K], tp[..., K:2 * K], tp[..., 2 * K:],
+                                               inverse=inverse, tail_bound=3.0, return_bins=True)
+        y, lad, bins = nf._lib.rqs(dev(x), dev(params), K, 'linear', 3.0, inverse=inverse, want_bins=True)
+        cum, _ = O._knots((tp[..., K:2 * K] if inverse else tp[..., :K]), 1e-3, -3.0, 3.0)
+        check_bins(bins, bo, x, cum, tol=3e-6)
+        y32, ld32 = O.rq_spline_linear_tails(x, tp[..., :K].float(), tp[..., K:2 * K].float(),
+                                             tp[..., 2 * K:].float(), inverse=inverse, tail_bound=3.0)
+        assert_close(y, yo, y32)
+        assert_close(lad, ldo.sum(1), ld32.sum(1))
+
+
+def test_rqs_empty_and_errors(nf):
+    x = torch.empty(0, 8, device='cuda')
+    y, lad, _ = nf._lib.rqs(x, torch.empty(0, 8 * 23, device='cuda'), 8, 'linear', 3.0)
+    assert y.shape == (0, 8) and lad.shape == (0,)
+    with pytest.raises(ValueError):            # reference: ValueError, rational_quadratic.py:66-69
+        nf._lib.rqs(torch.zeros(2, 2, device='cuda'), torch.zeros(2, 2 * 23, device='cuda'), 8, 'linear', 3.0,
+                    min_bin_width=0.2)
+    with pytest.raises(RuntimeError):          # params rows must be D*P long
+        nf._lib.rqs(torch.zeros(2, 2, device='cuda'), torch.zeros(2, 50, device='cuda'), 8, 'linear', 3.0)
+    with pytest.raises(RuntimeError):          # CPU tensors are refused: no fallback path
+        nf._lib.rqs(torch.zeros(2, 2), torch.zeros(2, 46), 8, 'linear', 3.0)
+
+
+def test_rqs_roundtrip_at_scale(nf):
+    """Size-independent properties at a cfg-3-sized launch (16384 x 784 elements): inverse(forward(x)) == x
+    and the two logdets cancel; accumulate=1 adds onto the existing logabsdet."""
+    B, D, K = 16384, 784, 8
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(B, D, device='cuda', generator=g)
+    params = torch.randn(B, D * 23, device='cuda', generator=g)
+    y, lad, _ = nf._lib.rqs(x, params, K, 'linear', 3.0)
+    x2, lad2, _ = nf._lib.rqs(y, params, K, 'linear', 3.0, inverse=True)
+    assert (x2 - x).abs().max().item() < 2e-4
+    assert (lad + lad2).abs().max().item() < 2e-2          # 784 terms of O(1), fp32
+    acc = lad.clone()
+    nf._lib.rqs(y, params, K, 'linear', 3.0, inverse=True, logabsdet=acc, accumulate=True, out=x2)
+    assert torch.allclose(acc, lad + lad2, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------- MADE
+@pytest.mark.parametrize('tag,kw', [('res', {}), ('ff', dict(use_residual_blocks=False)),
+                                    ('bn', dict(use_batch_norm=True)),
+                                    ('ffbn', dict(use_residual_blocks=False, use_batch_norm=True)),
+                                    ('nb3', dict(num_blocks=3))])
+def test_made_small_golden(nf, tag, kw):
+    fx = load_golden('made_small_' + tag)
+    net = nf.MADE(features=6, hidden_features=16, output_multiplier=23, **kw)
+    net.load_state_dict(golden_state_dict(fx), strict=True)        # the reference's own state_dict
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(dev(fx['x']))
+    assert rel_err(y.cpu(), fx['y64']) < TOL
+
+
+def test_made_context_golden(nf):
+    fx = load_golden('made_small_ctx')
+    net = nf.MADE(features=6, hidden_features=16, context_features=5, output_multiplier=2)
+    net.load_state_dict(golden_state_dict(fx), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(dev(fx['x']), dev(fx['context']))
+    assert rel_err(y.cpu(), fx['y32']) < TOL
+
+
+@pytest.mark.parametrize('tag', ['D64_H128_m23', 'D64_H128_m23_n01', 'D784_H512_m23', 'D784_H512_m2',
+                                 'D5_H32_m23', 'D1_H8_m23'])
+def test_made_seeded_golden(nf, tag):
+    fx = load_golden('made_' + tag)
+    D, H, mult, scale = int(fx['features']), int(fx['hidden']), int(fx['mult']), float(fx['scale'])
+    sd = O.seeded_made_state_dict(D, H, mult, seed=int(fx['seed']), scale=None if scale < 0 else scale, prefix='')
+    net = nf.MADE(features=D, hidden_features=H, output_multiplier=mult)
+    for k, v in net.state_dict().items():          # our masks are the reference's masks
+        if k.endswith('.mask'):
+            assert torch.equal(v.sum(1).to(torch.int32), T(fx['masksum/' + k.replace('.', '/')])), k
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(dev(fx['x']))
+    assert rel_err(y.cpu(), fx['y64']) < TOL
+
+
+def test_masked_linear_ragged_vs_oracle(nf):
+    """Rows/cols/K that are not tile multiples, unaligned K, ReLU prologue, residual epilogue."""
+    g = torch.Generator().manual_seed(9)
+    for (B, K, N) in [(1, 3, 5), (130, 33, 129), (257, 784, 300), (64, 50, 18032 // 8)]:
+        W = torch.randn(N, K, generator=g) * 0.2
+        mask = (torch.rand(N, K, generator=g) > 0.4).float()
+        bias = torch.randn(N, generator=g)
+        x = torch.randn(B, K, generator=g)
+        res = torch.randn(B, N, generator=g)
+        want = torch.relu(x.double()) @ (W * mask).double().t() + bias.double() + res.double()
+        pl = nf._lib.PackedLinear(W.cuda(), mask.cuda(), bias.cuda())
+        got = nf._lib.masked_linear(x.cuda(), pl, residual=res.cuda(), relu_in=True)
+        assert rel_err(got.cpu(), want) < TOL
+
+
+# ------------------------------------------------------------------------------- RQ-spline MAF
+def _load_layers(nf, sd_list, D, H, K, Tb):
+    layers = []
+    for sd in sd_list:
+        t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+            features=D, hidden_features=H, num_bins=K, tails='linear', tail_bound=Tb, num_blocks=2)
+        t.load_state_dict(sd, strict=True)
+        layers.append(t)
+    return layers
+
+
+def test_rq_ar_small_golden(nf):
+    fx = load_golden('rqar_small')
+    K, Tb, D, H = int(fx['num_bins']), float(fx['tail_bound']), int(fx['features']), int(fx['hidden'])
+    sd = golden_state_dict(fx)
+    layers = _load_layers(nf, [O.split_state_dict(sd, j) for j in range(3)], D, H, K, Tb)
+    comp = nf.CompositeTransform(layers).cuda().eval()
+    x = dev(fx['x'])
+    with torch.no_grad():
+        y1, ld1, bins1 = layers[0].forward_with_bins(x)
+        y, ld = comp(x)
+        flow = nf.BaseNeuralSplineFlow(comp, nf.StandardNormal([D], device='cuda'))
+        logp = flow.log_prob(x)
+        xs, lds = comp.inverse(dev(fx['z']))
+    params = O.made_forward(O.split_state_dict(sd, 0), T(fx['x']).double().float(), 'autoregressive_net.')
+    cum, _ = O._knots(params.view(-1, D, 3 * K - 1)[..., :K].double(), 1e-3, -Tb, Tb)
+    check_bins(bins1, T(fx['bins1']), T(fx['x']), cum, tol=3e-6)
+    assert_close(y1, fx['y1'], tol=2 * TOL)
+    assert_close(ld1, fx['ld1'], tol=2 * TOL)
+    assert_close(y, fx['y64'], fx['y'])
+    assert_close(ld, fx['ld64'], fx['ld'])
+    assert_close(logp, fx['logp'], tol=4 * TOL)       # this x2-scaled toy model: reference fp32 floor 3.5e-5
+    # inverse (D sequential passes): bounded by the reference's own fp32-vs-fp64 distance on this model
+    floor = max(rel_err(fx['xs'], fx['xs64']), TOL)
+    assert rel_err(xs.cpu(), fx['xs64']) < 4 * floor
+    assert rel_err(lds.cpu(), fx['lds64']) < 4 * max(rel_err(fx['lds'], fx['lds64']), TOL)
+
+
+def test_rq_ar_cfg3_golden(nf):
+    """5 x (D=784, H=512, K=8, T=3): forward, logdet, log_prob; one-layer inverse (784 passes)."""
+    fx = load_golden('rqar_cfg3')
+    K, Tb, D, H = int(fx['num_bins']), float(fx['tail_bound']), int(fx['features']), int(fx['hidden'])
+    sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=int(s)) for s in fx['seeds']]
+    layers = _load_layers(nf, sds, D, H, K, Tb)
+    comp = nf.CompositeTransform(layers).cuda().eval()
+    x = dev(fx['x'])
+    with torch.no_grad():
+        y1, ld1, bins1 = layers[0].forward_with_bins(x)
+        y, ld = comp(x)
+        logp = nf.BaseNeuralSplineFlow(comp, nf.StandardNormal([D], device='cuda')).log_prob(x)
+        xs1, lds1 = layers[0].inverse(dev(fx['zi']))
+    params = O.made_forward(sds[0], T(fx['x']), 'autoregressive_net.')
+    cum, _ = O._knots(params.view(-1, D, 3 * K - 1)[..., :K].double(), 1e-3, -Tb, Tb)
+    flips = check_bins(bins1, T(fx['bins1']), T(fx['x']), cum, tol=3e-6)
+    assert flips <= 2
+    assert rel_err(y1.cpu(), fx['y1']) < TOL
+    assert rel_err(y.cpu(), fx['y64']) < 2 * TOL
+    assert rel_err(ld.cpu(), fx['ld64']) < TOL
+    assert rel_err(logp.cpu(), fx['logp64']) < TOL
+    floor = max(rel_err(fx['xs1'], fx['xs1_64']), TOL)
+    assert rel_err(xs1.cpu(), fx['xs1_64']) < 4 * floor
+    assert rel_err(lds1.cpu(), fx['lds1_64']) < TOL * 10
+
+
+def test_rq_ar_roundtrip_and_chunking(nf):
+    """inverse(forward(x)) == x on a well-conditioned (default-init) layer, and a batch larger than
+    one launch group gives the same rows as the same rows evaluated alone."""
+    from normalizing_flows_amd import transforms as tr
+    torch.manual_seed(3)
+    D, H, K = 24, 64, 8
+    t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, num_bins=K, tails='linear',
+                                                                   tail_bound=3.).cuda().eval()
+    x = torch.randn(300, D, device='cuda')
+    with torch.no_grad():
+        y, ld = t(x)
+        x2, ld2 = t.inverse(y)
+        old = tr.CHUNK_ROWS
+        tr.CHUNK_ROWS = 128
+        try:
+            yc, ldc = t(x)
+        finally:
+            tr.CHUNK_ROWS = old
+    assert (x2 - x).abs().max().item() < 1e-4 and (ld + ld2).abs().max().item() < 1e-3
+    assert torch.equal(yc, y) and torch.equal(ldc, ld)
+
+
+# ------------------------------------------------------------------------------- affine / coupling
+def test_affine_ar_golden(nf):
+    fx = load_golden('affine_ar')
+    t = nf.MaskedAffineAutoregressiveTransform(features=int(fx['features']), hidden_features=int(fx['hidden']))
+    t.load_state_dict(golden_state_dict(fx), strict=True)
+    t = t.cuda().eval()
+    with torch.no_grad():
+        y, ld = t(dev(fx['x']))
+        xs, lds = t.inverse(dev(fx['z']))
+    assert rel_err(y.cpu(), fx['y64']) < TOL and rel_err(ld.cpu(), fx['ld64']) < TOL
+    assert rel_err(xs.cpu(), fx['xs']) < 10 * TOL and rel_err(lds.cpu(), fx['lds']) < TOL
+
+
+def _coupling_stack(nf, fx, kind):
+    D, Hn, L = int(fx['features']), int(fx['hidden']), int(fx['n_layers'])
+    layers = []
+    for j in range(L):
+        mask = torch.zeros(D)
+        mask[(0 if j % 2 == 0 else 1)::2] = 1          # create_alternating_binary_mask(even = j even)
+        net_fn = lambda i, o: nf.ResidualNet(i, o, hidden_features=Hn, num_blocks=2)
+        if kind == 'affine':
+            layers.append(nf.AffineCouplingTransform(mask, net_fn))
+        else:
+            layers.append(nf.PiecewiseRationalQuadraticCouplingTransform(
+                mask, net_fn, num_bins=int(fx['num_bins']), tails=kind, tail_bound=float(fx['tail_bound'])))
+    comp = nf.CompositeTransform(layers)
+    comp.load_state_dict(golden_state_dict(fx), strict=True)
+    return comp.cuda().eval()
+
+
+@pytest.mark.parametrize('tag', ['linear', 'notails'])
+def test_rq_coupling_golden(nf, tag):
+    fx = load_golden('rq_coupling_' + tag)
+    comp = _coupling_stack(nf, fx, 'linear' if tag == 'linear' else None)
+    with torch.no_grad():
+        y, ld = comp(dev(fx['x']))
+        xi, ldi = comp.inverse(dev(fx['y']))
+    assert rel_err(y.cpu(), fx['y64']) < TOL and rel_err(ld.cpu(), fx['ld64']) < TOL
+    assert rel_err(xi.cpu(), fx['x']) < 10 * TOL and rel_err(ldi.cpu(), -fx['ld64']) < TOL
+
+
+def test_affine_coupling_golden(nf):
+    fx = load_golden('affine_coupling')
+    comp = _coupling_stack(nf, fx, 'affine')
+    with torch.no_grad():
+        y, ld = comp(dev(fx['x']))
+        xi, ldi = comp.inverse(dev(fx['y']))
+    assert rel_err(y.cpu(), fx['y64']) < TOL and rel_err(ld.cpu(), fx['ld64']) < TOL
+    assert rel_err(xi.cpu(), fx['x']) < 10 * TOL and rel_err(ldi.cpu(), -fx['ld64']) < TOL
+
+
+def test_module_errors(nf):
+    t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(6, 16, num_bins=4, tails='linear').cuda().eval()
+    with torch.no_grad():
+        with pytest.raises(ValueError):                      # reference transforms.py:84-86 wording
+            t(torch.zeros(3, 7, device='cuda'))
+    with pytest.raises(NotImplementedError):                 # no silent autograd fallback
+        t(torch.zeros(3, 6, device='cuda'))
+    with pytest.raises(ValueError):
+        nf.MADE(4, 8, random_mask=True)                      # made.py:305-306
