@@ -7,6 +7,7 @@ from .resnet import ResidualNet, ResidualBlock
 from .transforms import CompositeTransform, AutoregressiveTransform, MaskedAffineAutoregressiveTransform, \
     MaskedPiecewiseRationalQuadraticAutoregressiveTransform, CouplingTransform, AffineCouplingTransform, \
     PiecewiseRationalQuadraticCouplingTransform
+from . import parallel
 from .distributions import Distribution, StandardNormal, BaseNeuralSplineFlow, Flow
 
 __all__ = [n for n in dir() if not n.startswith('_')]

@@ -129,10 +129,13 @@ def masked_linear(x, pl, residual=None, in_scale=None, in_shift=None, relu_in=Fa
         out = torch.empty((B, pl.out), dtype=torch.float32, device=x.device)
     yp, ys = _rows(out, 'out')
     rp, rs = (None, 0) if residual is None else _rows(_dev(residual, 'residual'), 'residual')
-    with torch.cuda.device(x.device):
-        _check(lib.nf_masked_linear_fwd(xp, xs, pl.packed.data_ptr(), pl.ktab.data_ptr(), _ptr(pl.bias), rp, rs,
+    def launch():
+        return lib.nf_masked_linear_fwd(xp, xs, pl.packed.data_ptr(), pl.ktab.data_ptr(), _ptr(pl.bias), rp, rs,
                                         _ptr(in_scale), _ptr(in_shift), yp, ys, B, pl.inp, pl.out,
-                                        int(relu_in), int(relu_out), pl.dtype, _stream()), 'nf_masked_linear_fwd')
+                                        int(relu_in), int(relu_out), pl.dtype, _stream())
+    with torch.cuda.device(x.device):
+        code = launch() if _timer is None else _timer.record(('masked_linear', pl.inp, pl.out, B), launch)
+        _check(code, 'nf_masked_linear_fwd')
     return out
 
 
@@ -154,11 +157,14 @@ def rqs(x, params, num_bins, tails, tail_bound, inverse=False, pre_div=1.0, feat
         logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
         accumulate = False
     bins = torch.empty((B, D), dtype=torch.int32, device=x.device) if want_bins else None
-    with torch.cuda.device(x.device):
-        _check(lib.nf_rqs_fwd(xp, xs, _ptr(feat_index), pp, ps, float(pre_div), yp, ys, logabsdet.data_ptr(),
+    def launch():
+        return lib.nf_rqs_fwd(xp, xs, _ptr(feat_index), pp, ps, float(pre_div), yp, ys, logabsdet.data_ptr(),
                               int(accumulate), _ptr(bins), B, D, int(num_bins), 1 if tails == 'linear' else 0,
                               float(tail_bound), float(min_bin_width), float(min_bin_height),
-                              float(min_derivative), int(inverse), _stream()), 'nf_rqs_fwd')
+                              float(min_derivative), int(inverse), _stream())
+    with torch.cuda.device(x.device):
+        code = launch() if _timer is None else _timer.record(('rqs', D, int(num_bins), B), launch)
+        _check(code, 'nf_rqs_fwd')
     return out, logabsdet, bins
 
 
@@ -181,3 +187,33 @@ def affine(x, params, layout, inverse=False, feat_index=None, out=None, logabsde
         _check(lib.nf_affine_fwd(xp, xs, _ptr(feat_index), pp, ps, int(layout), yp, ys, logabsdet.data_ptr(),
                                  int(accumulate), B, D, int(inverse), _stream()), 'nf_affine_fwd')
     return out, logabsdet
+
+
+# ------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """Optional HIP-event timing of individual launches on the stream they are launched on
+    (bench.py's roofline leg).  Off unless a bench installs one with `set_timer`."""
+
+    def __init__(self):
+        self.events = {}
+
+    def record(self, key, launch):
+        s = torch.cuda.current_stream()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        r = launch()
+        b.record(s)
+        self.events.setdefault(key, []).append((a, b))
+        return r
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t

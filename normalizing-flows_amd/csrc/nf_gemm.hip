@@ -263,9 +263,10 @@ extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const 
                                     const float* bias, const float* residual, int64_t residual_row_stride,
                                     const float* in_scale, const float* in_shift, float* y, int64_t y_row_stride,
                                     int64_t B, int in, int out, int relu_in, int relu_out, int dtype, void* stream) {
+    if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
+    if (B == 0) return NF_OK;
     if (!x || !packed_w || !ktab || !y) return NF_ERR_NULL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return NF_ERR_NULL;
-    if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (x_row_stride < in || y_row_stride < out || (residual && residual_row_stride < out)) return NF_ERR_LAYOUT;
     if (dtype != NF_DTYPE_F32) return NF_ERR_DTYPE;
     if (B == 0) return NF_OK;

@@ -354,10 +354,10 @@ extern "C" int nf_rqs_fwd(const float* x, int64_t x_row_stride, const int32_t* f
                           int32_t* bin_idx, int64_t B, int D, int K, int tails, double tail_bound,
                           double min_bin_width, double min_bin_height, double min_derivative,
                           int inverse, void* stream) {
-    if (!x || !params || !y || !logabsdet) return NF_ERR_NULL;
     if (B < 0 || D <= 0 || K <= 0 || K > 32) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
-    if (B == 0) return NF_OK;
+    if (B == 0) return NF_OK;          // empty batch: nothing to read, pointers may be NULL
+    if (!x || !params || !y || !logabsdet) return NF_ERR_NULL;
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
     if (param_row_stride != (int64_t)D * P) return NF_ERR_LAYOUT;
     if (x_row_stride < D || y_row_stride < D) return NF_ERR_LAYOUT;
@@ -389,9 +389,10 @@ extern "C" int nf_affine_fwd(const float* x, int64_t x_row_stride, const int32_t
                              const float* params, int64_t param_row_stride, int layout,
                              float* y, int64_t y_row_stride, float* logabsdet, int accumulate,
                              int64_t B, int D, int inverse, void* stream) {
-    if (!x || !params || !y || !logabsdet) return NF_ERR_NULL;
     if (B < 0 || D <= 0) return NF_ERR_SHAPE;
     if (layout != NF_AFFINE_INTERLEAVED && layout != NF_AFFINE_BLOCKED) return NF_ERR_DTYPE;
+    if (B == 0) return NF_OK;
+    if (!x || !params || !y || !logabsdet) return NF_ERR_NULL;
     if (param_row_stride < 2 * (int64_t)D || x_row_stride < D || y_row_stride < D) return NF_ERR_LAYOUT;
     if (layout == NF_AFFINE_INTERLEAVED && ((((uintptr_t)params) & 7) || (param_row_stride & 1))) return NF_ERR_LAYOUT;
     if (B == 0) return NF_OK;
