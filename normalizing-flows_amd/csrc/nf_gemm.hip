@@ -64,7 +64,53 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int64_t& tm, in
     tn = (int)(in / gm);
 }
 
-__global__ __launch_bounds__(GT) void masked_linear_f32_kernel(const GemmArgs g) {
+// load_one only issues the loads; everything that consumes a loaded value lives in store_one so that
+// no s_waitcnt lands between the prefetch and the MFMAs it is meant to hide under.  The staged
+// registers are eight named float4 variables: kept in arrays, hipcc (ROCm 7.2) leaves them in scratch.
+template <bool VEC_A>
+__device__ __forceinline__ void load_one(const GemmArgs& g, const float* arow, const float* brow, int k, int kt,
+                                         float4& a, float4& b) {
+    if (VEC_A) {
+        a = *reinterpret_cast<const float4*>(arow + min(k, g.K - 4));
+    } else {
+        a.x = arow[min(k, g.K - 1)];
+        a.y = arow[min(k + 1, g.K - 1)];
+        a.z = arow[min(k + 2, g.K - 1)];
+        a.w = arow[min(k + 3, g.K - 1)];
+    }
+    b = *reinterpret_cast<const float4*>(brow + kt * BK);
+}
+
+template <bool IN_AFFINE, bool RELU_IN>
+__device__ __forceinline__ void store_one(const GemmArgs& g, float* As, float* Bs, int k, float4 sc, float4 sh,
+                                          float4 a, float4 b) {
+    if (IN_AFFINE) {
+        a.x = a.x * sc.x + sh.x;
+        a.y = a.y * sc.y + sh.y;
+        a.z = a.z * sc.z + sh.z;
+        a.w = a.w * sc.w + sh.w;
+    }
+    if (RELU_IN) {
+        a.x = fmaxf(a.x, 0.f);
+        a.y = fmaxf(a.y, 0.f);
+        a.z = fmaxf(a.z, 0.f);
+        a.w = fmaxf(a.w, 0.f);
+    }
+    // zero the K tail (the packed weights are zero there too, but 0 * inf/NaN must not appear)
+    a.x = k < g.K ? a.x : 0.f;
+    a.y = k + 1 < g.K ? a.y : 0.f;
+    a.z = k + 2 < g.K ? a.z : 0.f;
+    a.w = k + 3 < g.K ? a.w : 0.f;
+    *reinterpret_cast<float4*>(As) = a;
+    *reinterpret_cast<float4*>(Bs) = b;
+}
+
+// VEC_A: x rows are 16-byte aligned and K % 4 == 0 (one 16-byte load per staged float4).
+// IN_AFFINE: per-input-feature scale/shift (eval-mode BatchNorm) applied while staging.
+// Loads are unconditional on clamped addresses and masked with selects afterwards: a branch around
+// a load makes hipcc drain vmcnt(0) after each one, which serialises the whole prefetch.
+template <bool VEC_A, bool IN_AFFINE, bool RELU_IN>
+__global__ __launch_bounds__(GT, 2) void masked_linear_f32_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
 
@@ -87,68 +133,50 @@ __global__ __launch_bounds__(GT) void masked_linear_f32_kernel(const GemmArgs g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // staging map: float4 index v = tid + 256*i -> row v>>3, k-offset 4*(v&7)
-    float4 ra[4], rb[4];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = tid + GT * i;
-            const int row = v >> 3, kc = (v & 7) * 4;
-            const int64_t m = m0 + row;
-            const int k = k0 + kc;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < g.M) {
-                const float* src = g.x + m * g.ldx + k;
-                if (g.vec_a) {
-                    if (k < g.K) a = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (k < g.K) a.x = src[0];
-                    if (k + 1 < g.K) a.y = src[1];
-                    if (k + 2 < g.K) a.z = src[2];
-                    if (k + 3 < g.K) a.w = src[3];
-                }
-                if (g.in_scale) {
-                    // K % 4 != 0 tails: scale/shift beyond K multiply zeros; guard the loads
-                    float sc[4], sh[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool ok = k + j < g.K;
-                        sc[j] = ok ? g.in_scale[k + j] : 0.f;
-                        sh[j] = ok ? g.in_shift[k + j] : 0.f;
-                    }
-                    a.x = a.x * sc[0] + sh[0];
-                    a.y = a.y * sc[1] + sh[1];
-                    a.z = a.z * sc[2] + sh[2];
-                    a.w = a.w * sc[3] + sh[3];
-                }
-                if (g.relu_in) {
-                    a.x = fmaxf(a.x, 0.f);
-                    a.y = fmaxf(a.y, 0.f);
-                    a.z = fmaxf(a.z, 0.f);
-                    a.w = fmaxf(a.w, 0.f);
-                }
-            }
-            ra[i] = a;
-            rb[i] = *reinterpret_cast<const float4*>(g.w + (int64_t)(n0 + row) * g.kpad + k);
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = tid + GT * i;
-            const int row = v >> 3, kc = (v & 7) * 4;
-            *reinterpret_cast<float4*>(&As[row * LDS_LD + kc]) = ra[i];
-            *reinterpret_cast<float4*>(&Bs[row * LDS_LD + kc]) = rb[i];
-        }
-    };
+    // staging map: float4 index v = tid + 256*i -> row v>>3 (= srow + 32*i), k-offset 4*(v&7)
+    const int srow = tid >> 3, skc = (tid & 7) * 4;
+    // rows past M re-read the last row; they are never stored
+    const float* ar0 = g.x + min(m0 + srow, g.M - 1) * g.ldx;
+    const float* ar1 = g.x + min(m0 + srow + 32, g.M - 1) * g.ldx;
+    const float* ar2 = g.x + min(m0 + srow + 64, g.M - 1) * g.ldx;
+    const float* ar3 = g.x + min(m0 + srow + 96, g.M - 1) * g.ldx;
+    const float* br0 = g.w + (int64_t)(n0 + srow) * g.kpad + skc;
+    const float* br1 = br0 + (int64_t)32 * g.kpad;
+    const float* br2 = br0 + (int64_t)64 * g.kpad;
+    const float* br3 = br0 + (int64_t)96 * g.kpad;
+    float* as0 = &As[srow * LDS_LD + skc];
+    float* bs0 = &Bs[srow * LDS_LD + skc];
+    float4 a0, a1, a2, a3, b0, b1, b2, b3;
 
-    if (kt_begin < kt_end) load_tile(kt_begin);
+#define NF_LOAD_TILE(KT)                                                  \
+    do {                                                                  \
+        const int kt_ = (KT);                                             \
+        const int k_ = kt_ * BK + skc;                                    \
+        load_one<VEC_A>(g, ar0, br0, k_, kt_, a0, b0);                    \
+        load_one<VEC_A>(g, ar1, br1, k_, kt_, a1, b1);                    \
+        load_one<VEC_A>(g, ar2, br2, k_, kt_, a2, b2);                    \
+        load_one<VEC_A>(g, ar3, br3, k_, kt_, a3, b3);                    \
+    } while (0)
+
+    if (kt_begin < kt_end) NF_LOAD_TILE(kt_begin);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         __syncthreads();             // everyone done reading the previous tile
-        store_tile();
+        {
+            const int k = kt * BK + skc;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (IN_AFFINE) {
+                const int k0 = min(k, g.K - 1), k1 = min(k + 1, g.K - 1), k2 = min(k + 2, g.K - 1), k3 = min(k + 3, g.K - 1);
+                sc = make_float4(g.in_scale[k0], g.in_scale[k1], g.in_scale[k2], g.in_scale[k3]);
+                sh = make_float4(g.in_shift[k0], g.in_shift[k1], g.in_shift[k2], g.in_shift[k3]);
+            }
+            store_one<IN_AFFINE, RELU_IN>(g, as0, bs0, k, sc, sh, a0, b0);
+            store_one<IN_AFFINE, RELU_IN>(g, as0 + 32 * LDS_LD, bs0 + 32 * LDS_LD, k, sc, sh, a1, b1);
+            store_one<IN_AFFINE, RELU_IN>(g, as0 + 64 * LDS_LD, bs0 + 64 * LDS_LD, k, sc, sh, a2, b2);
+            store_one<IN_AFFINE, RELU_IN>(g, as0 + 96 * LDS_LD, bs0 + 96 * LDS_LD, k, sc, sh, a3, b3);
+        }
         __syncthreads();
-        if (kt + 1 < kt_end) load_tile(kt + 1);      // in flight under the MFMAs below
+        NF_LOAD_TILE(min(kt + 1, kt_end - 1));   // in flight under the MFMAs below (the last one is a re-read)
+        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch issue ABOVE the MFMAs
 
         const int frow = lane & 31, fk = (lane >> 5) * 4;
 #pragma unroll
@@ -170,6 +198,8 @@ __global__ __launch_bounds__(GT) void masked_linear_f32_kernel(const GemmArgs g)
                 }
         }
     }
+
+#undef NF_LOAD_TILE
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -279,6 +309,18 @@ extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const 
     g.vec_a = (in % 4 == 0) && (x_row_stride % 4 == 0) && (((uintptr_t)x & 15) == 0);
     const int64_t grid = g.m_tiles * g.n_tiles;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    hipLaunchKernelGGL(masked_linear_f32_kernel, dim3((int)grid), dim3(GT), 0, (hipStream_t)stream, g);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 gr((int)grid), bl(GT);
+    const int sel = (g.vec_a ? 4 : 0) | (in_scale ? 2 : 0) | (relu_in ? 1 : 0);
+    switch (sel) {
+        case 0: hipLaunchKernelGGL((masked_linear_f32_kernel<false, false, false>), gr, bl, 0, s, g); break;
+        case 1: hipLaunchKernelGGL((masked_linear_f32_kernel<false, false, true>), gr, bl, 0, s, g); break;
+        case 2: hipLaunchKernelGGL((masked_linear_f32_kernel<false, true, false>), gr, bl, 0, s, g); break;
+        case 3: hipLaunchKernelGGL((masked_linear_f32_kernel<false, true, true>), gr, bl, 0, s, g); break;
+        case 4: hipLaunchKernelGGL((masked_linear_f32_kernel<true, false, false>), gr, bl, 0, s, g); break;
+        case 5: hipLaunchKernelGGL((masked_linear_f32_kernel<true, false, true>), gr, bl, 0, s, g); break;
+        case 6: hipLaunchKernelGGL((masked_linear_f32_kernel<true, true, false>), gr, bl, 0, s, g); break;
+        default: hipLaunchKernelGGL((masked_linear_f32_kernel<true, true, true>), gr, bl, 0, s, g); break;
+    }
     return nf_launch_status();
 }

@@ -22,8 +22,9 @@ DEFAULT_MIN_BIN_HEIGHT = 1e-3
 DEFAULT_MIN_DERIVATIVE = 1e-3
 
 # Rows evaluated per launch group.  The conditioner output of one D=784, K=8 layer is 72 KB per
-# sample; 32768 rows keep that intermediate at 2.4 GB instead of 19 GB for a 256k batch.
-CHUNK_ROWS = 32768
+# sample; 131072 rows keep that intermediate at 9.5 GB (of 288 GB) while every launch still fills the
+# 256 CUs many times over (few, large launches: small grids lose a third of the chip to tail effects).
+CHUNK_ROWS = 131072
 
 
 def _check_2d(inputs, features):
