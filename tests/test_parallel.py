@@ -1,0 +1,61 @@
+"""The N>1 path on CPU: two gloo ranks shard a batch, evaluate their shard (here with the CPU oracle
+standing in for the per-rank kernel work, which needs no communication) and all-reduce the
+[sum log p, count] pair; the result must equal the single-process mean."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, n, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from normalizing_flows_amd import parallel
+        from oracle import nf_oracle as O
+        torch.set_num_threads(2)
+        D, H, K = 12, 24, 4
+        sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=7)
+        x = torch.randn(n, D, generator=torch.Generator().manual_seed(3))
+
+        def log_prob(v):
+            return O.flow_log_prob([lambda u: O.rq_autoregressive_forward(sd, u, K, 3.0)], v)
+
+        lp, lo, hi, mean = parallel.sharded_log_prob(log_prob, x)
+        assert lp.shape[0] == hi - lo
+        if rank == 0:
+            torch.save({'mean': mean, 'lo': lo, 'hi': hi}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_exactly():
+    from normalizing_flows_amd import parallel
+    for n in (0, 1, 7, 8, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize('n', [64, 37])
+def test_two_rank_log_likelihood_reduction(tmp_path, n):
+    from oracle import nf_oracle as O
+    out = str(tmp_path / 'r0.pt')
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, n, out), nprocs=2, join=True)
+    got = torch.load(out)
+    D, H, K = 12, 24, 4
+    sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=7)
+    x = torch.randn(n, D, generator=torch.Generator().manual_seed(3))
+    want = O.flow_log_prob([lambda u: O.rq_autoregressive_forward(sd, u, K, 3.0)], x).double().mean().item()
+    assert abs(got['mean'] - want) < 1e-5 * max(1.0, abs(want))
+    assert (got['lo'], got['hi']) == (0, (n + 1) // 2)
