@@ -221,6 +221,159 @@ __global__ __launch_bounds__(GT, 2) void masked_linear_f32_kernel(const GemmArgs
         }
 }
 
+// ---- bf16 matrix-core path (2e-2 contract) ------------------------------------------------------
+// Same block structure with v_mfma_f32_32x32x16_bf16: x is read as fp32 and rounded to bf16 (RNE,
+// v_cvt_pk_bf16_f32) while it is staged, the packed weights are bf16, accumulation and the epilogue
+// stay fp32.  K tile = 64; LDS rows are 64 bf16 + 8 pad = 144 bytes, the same conflict-free stride as
+// the fp32 kernel.  Lane l of a fragment holds A[row l&31][k = 8(l>>5) .. +7] (cdna guide, sec. 3).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BK16 = 64;
+constexpr int LDS_LD16 = BK16 + 8;      // bf16 elements per padded row
+
+template <bool VEC_A>
+__device__ __forceinline__ void load_one16(const GemmArgs& g, const float* arow, const __bf16* brow, int k, int kt,
+                                           float4& a_lo, float4& a_hi, bf16x8& b) {
+    if (VEC_A) {
+        const int kk = min(k, g.K - 8);
+        a_lo = *reinterpret_cast<const float4*>(arow + kk);
+        a_hi = *reinterpret_cast<const float4*>(arow + kk + 4);
+    } else {
+        a_lo.x = arow[min(k, g.K - 1)];
+        a_lo.y = arow[min(k + 1, g.K - 1)];
+        a_lo.z = arow[min(k + 2, g.K - 1)];
+        a_lo.w = arow[min(k + 3, g.K - 1)];
+        a_hi.x = arow[min(k + 4, g.K - 1)];
+        a_hi.y = arow[min(k + 5, g.K - 1)];
+        a_hi.z = arow[min(k + 6, g.K - 1)];
+        a_hi.w = arow[min(k + 7, g.K - 1)];
+    }
+    b = *reinterpret_cast<const bf16x8*>(brow + kt * BK16);
+}
+
+template <bool IN_AFFINE, bool RELU_IN>
+__device__ __forceinline__ void store_one16(const GemmArgs& g, __bf16* As, __bf16* Bs, int k, const float (&sc)[8],
+                                            const float (&sh)[8], float4 a_lo, float4 a_hi, bf16x8 b) {
+    float v[8] = {a_lo.x, a_lo.y, a_lo.z, a_lo.w, a_hi.x, a_hi.y, a_hi.z, a_hi.w};
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = v[j];
+        if (IN_AFFINE) t = t * sc[j] + sh[j];
+        if (RELU_IN) t = fmaxf(t, 0.f);
+        t = k + j < g.K ? t : 0.f;
+        o[j] = (__bf16)t;
+    }
+    *reinterpret_cast<bf16x8*>(As) = o;
+    *reinterpret_cast<bf16x8*>(Bs) = b;
+}
+
+template <bool VEC_A, bool IN_AFFINE, bool RELU_IN>
+__global__ __launch_bounds__(GT, 2) void masked_linear_bf16_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[BM * LDS_LD16];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[BN * LDS_LD16];
+
+    int64_t tm;
+    int tn;
+    tile_of_block(g, tm, tn);
+    const int64_t m0 = tm * BM;
+    const int n0 = tn * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ktab counts 32-wide K tiles; this kernel walks 64-wide ones
+    const int kt_begin = g.ktab[2 * tn] >> 1, kt_end = (g.ktab[2 * tn + 1] + 1) >> 1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // staging map: 16-byte (8 x bf16) chunk v = tid + 256*i -> row v>>3 (= srow + 32*i), k-offset 8*(v&7)
+    const int srow = tid >> 3, skc = (tid & 7) * 8;
+    const float* ar0 = g.x + min(m0 + srow, g.M - 1) * g.ldx;
+    const float* ar1 = g.x + min(m0 + srow + 32, g.M - 1) * g.ldx;
+    const float* ar2 = g.x + min(m0 + srow + 64, g.M - 1) * g.ldx;
+    const float* ar3 = g.x + min(m0 + srow + 96, g.M - 1) * g.ldx;
+    const __bf16* br0 = reinterpret_cast<const __bf16*>(g.w) + (int64_t)(n0 + srow) * g.kpad + skc;
+    const __bf16* br1 = br0 + (int64_t)32 * g.kpad;
+    const __bf16* br2 = br0 + (int64_t)64 * g.kpad;
+    const __bf16* br3 = br0 + (int64_t)96 * g.kpad;
+    __bf16* as0 = &As[srow * LDS_LD16 + skc];
+    __bf16* bs0 = &Bs[srow * LDS_LD16 + skc];
+    float4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h;
+    bf16x8 b0, b1, b2, b3;
+
+#define NF_LOAD_TILE16(KT)                                                \
+    do {                                                                  \
+        const int kt_ = (KT);                                             \
+        const int k_ = kt_ * BK16 + skc;                                  \
+        load_one16<VEC_A>(g, ar0, br0, k_, kt_, a0l, a0h, b0);            \
+        load_one16<VEC_A>(g, ar1, br1, k_, kt_, a1l, a1h, b1);            \
+        load_one16<VEC_A>(g, ar2, br2, k_, kt_, a2l, a2h, b2);            \
+        load_one16<VEC_A>(g, ar3, br3, k_, kt_, a3l, a3h, b3);            \
+    } while (0)
+
+    if (kt_begin < kt_end) NF_LOAD_TILE16(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();
+        {
+            const int k = kt * BK16 + skc;
+            float sc[8], sh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sc[j] = IN_AFFINE ? g.in_scale[min(k + j, g.K - 1)] : 1.f;
+                sh[j] = IN_AFFINE ? g.in_shift[min(k + j, g.K - 1)] : 0.f;
+            }
+            store_one16<IN_AFFINE, RELU_IN>(g, as0, bs0, k, sc, sh, a0l, a0h, b0);
+            store_one16<IN_AFFINE, RELU_IN>(g, as0 + 32 * LDS_LD16, bs0 + 32 * LDS_LD16, k, sc, sh, a1l, a1h, b1);
+            store_one16<IN_AFFINE, RELU_IN>(g, as0 + 64 * LDS_LD16, bs0 + 64 * LDS_LD16, k, sc, sh, a2l, a2h, b2);
+            store_one16<IN_AFFINE, RELU_IN>(g, as0 + 96 * LDS_LD16, bs0 + 96 * LDS_LD16, k, sc, sh, a3l, a3h, b3);
+        }
+        __syncthreads();
+        NF_LOAD_TILE16(min(kt + 1, kt_end - 1));
+        __builtin_amdgcn_sched_barrier(0);
+
+        const int frow = lane & 31, fk = (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[(wr * 64 + i * 32 + frow) * LDS_LD16 + ks * 16 + fk]);
+                b[i] = *reinterpret_cast<const bf16x8*>(&Bs[(wc * 64 + i * 32 + frow) * LDS_LD16 + ks * 16 + fk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#undef NF_LOAD_TILE16
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= g.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (g.res) v += g.res[row * g.ldr + col];
+                if (g.relu_out) v = fmaxf(v, 0.0f);
+                g.y[row * g.ldy + col] = v;
+            }
+        }
+}
+
 // ---- packing ---------------------------------------------------------------------------------
 __global__ void pack_f32_kernel(const float* __restrict__ W, const float* __restrict__ mask, int out, int in,
                                 int kpad, int64_t total, float* __restrict__ packed) {
@@ -233,6 +386,20 @@ __global__ void pack_f32_kernel(const float* __restrict__ W, const float* __rest
             if (mask) v *= mask[n * in + k];
         }
         packed[i] = v;
+    }
+}
+
+__global__ void pack_bf16_kernel(const float* __restrict__ W, const float* __restrict__ mask, int out, int in,
+                                 int kpad, int64_t total, __bf16* __restrict__ packed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / kpad;
+        const int k = (int)(i - n * kpad);
+        float v = 0.0f;
+        if (n < out && k < in) {
+            v = W[n * in + k];
+            if (mask) v *= mask[n * in + k];
+        }
+        packed[i] = (__bf16)v;
     }
 }
 
@@ -263,7 +430,7 @@ __global__ __launch_bounds__(256) void ktab_kernel(const float* __restrict__ mas
 }
 
 inline int n_tiles_of(int out) { return (out + BN - 1) / BN; }
-inline int kpad_of(int in) { return (in + BK - 1) / BK * BK; }
+inline int kpad_of(int in) { return (in + BK16 - 1) / BK16 * BK16; }   // whole K tiles of either kernel
 
 }  // namespace
 
@@ -279,12 +446,15 @@ extern "C" int nf_made_pack(const float* W, const float* mask, int out, int in, 
                             int32_t* ktab, void* stream) {
     if (!W || !packed || !ktab) return NF_ERR_NULL;
     if (out <= 0 || in <= 0) return NF_ERR_SHAPE;
-    if (dtype != NF_DTYPE_F32) return NF_ERR_DTYPE;
+    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
     hipStream_t s = (hipStream_t)stream;
     const int kpad = kpad_of(in);
     const int64_t total = (int64_t)n_tiles_of(out) * BN * kpad;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_f32_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, kpad, total, (float*)packed);
+    if (dtype == NF_DTYPE_F32)
+        hipLaunchKernelGGL(pack_f32_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, kpad, total, (float*)packed);
+    else
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, kpad, total, (__bf16*)packed);
     hipLaunchKernelGGL(ktab_kernel, dim3(n_tiles_of(out)), dim3(256), 0, s, mask, out, in, kpad, ktab);
     return nf_launch_status();
 }
@@ -298,20 +468,33 @@ extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const 
     if (!x || !packed_w || !ktab || !y) return NF_ERR_NULL;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return NF_ERR_NULL;
     if (x_row_stride < in || y_row_stride < out || (residual && residual_row_stride < out)) return NF_ERR_LAYOUT;
-    if (dtype != NF_DTYPE_F32) return NF_ERR_DTYPE;
-    if (B == 0) return NF_OK;
+    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
     GemmArgs g;
     g.x = x; g.ldx = x_row_stride; g.w = (const float*)packed_w; g.kpad = kpad_of(in); g.ktab = ktab;
     g.bias = bias; g.res = residual; g.ldr = residual_row_stride; g.in_scale = in_scale; g.in_shift = in_shift;
     g.y = y; g.ldy = y_row_stride; g.M = B; g.N = out; g.K = in; g.relu_in = relu_in; g.relu_out = relu_out;
     g.n_tiles = n_tiles_of(out);
     g.m_tiles = (B + BM - 1) / BM;
-    g.vec_a = (in % 4 == 0) && (x_row_stride % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    const int vec = dtype == NF_DTYPE_BF16 ? 8 : 4;      // floats per staged chunk
+    g.vec_a = (in % vec == 0) && (x_row_stride % 4 == 0) && (((uintptr_t)x & 15) == 0);
     const int64_t grid = g.m_tiles * g.n_tiles;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const dim3 gr((int)grid), bl(GT);
     const int sel = (g.vec_a ? 4 : 0) | (in_scale ? 2 : 0) | (relu_in ? 1 : 0);
+    if (dtype == NF_DTYPE_BF16) {
+        switch (sel) {
+            case 0: hipLaunchKernelGGL((masked_linear_bf16_kernel<false, false, false>), gr, bl, 0, s, g); break;
+            case 1: hipLaunchKernelGGL((masked_linear_bf16_kernel<false, false, true>), gr, bl, 0, s, g); break;
+            case 2: hipLaunchKernelGGL((masked_linear_bf16_kernel<false, true, false>), gr, bl, 0, s, g); break;
+            case 3: hipLaunchKernelGGL((masked_linear_bf16_kernel<false, true, true>), gr, bl, 0, s, g); break;
+            case 4: hipLaunchKernelGGL((masked_linear_bf16_kernel<true, false, false>), gr, bl, 0, s, g); break;
+            case 5: hipLaunchKernelGGL((masked_linear_bf16_kernel<true, false, true>), gr, bl, 0, s, g); break;
+            case 6: hipLaunchKernelGGL((masked_linear_bf16_kernel<true, true, false>), gr, bl, 0, s, g); break;
+            default: hipLaunchKernelGGL((masked_linear_bf16_kernel<true, true, true>), gr, bl, 0, s, g); break;
+        }
+        return nf_launch_status();
+    }
     switch (sel) {
         case 0: hipLaunchKernelGGL((masked_linear_f32_kernel<false, false, false>), gr, bl, 0, s, g); break;
         case 1: hipLaunchKernelGGL((masked_linear_f32_kernel<false, false, true>), gr, bl, 0, s, g); break;

@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
 def test_argument_errors_before_launch():
     lib = nf._lib.load()
     assert lib.nf_made_packed_bytes(18032, 512, 0) == 141 * 128 * 512 * 4
-    assert lib.nf_made_packed_bytes(5, 3, 0) == 128 * 32 * 4
+    assert lib.nf_made_packed_bytes(5, 3, 0) == 128 * 64 * 4
+    assert lib.nf_made_packed_bytes(5, 3, 1) == 128 * 64 * 2
     assert lib.nf_made_ktab_len(18032) == 2 * 141
     # empty batches are legal and launch nothing, even with NULL pointers
     assert lib.nf_rqs_fwd(None, 8, None, None, 8 * 23, 1.0, None, 8, None, 0, None, 0, 8, 8, 1, 3.0,

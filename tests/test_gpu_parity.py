@@ -297,6 +297,44 @@ def test_rq_ar_roundtrip_and_chunking(nf):
     assert torch.equal(yc, y) and torch.equal(ldc, ld)
 
 
+# ------------------------------------------------------------------------------- bf16-MFMA mode
+def test_bf16_mode_cfg3_within_2e_2(nf):
+    """MADE GEMMs on bf16 MFMA (x and weights rounded to bf16, fp32 accumulate): log_prob and outputs
+    within the 2e-2 contract of north_star; the spline itself stays fp32."""
+    fx = load_golden('rqar_cfg3')
+    K, Tb, D, H = int(fx['num_bins']), float(fx['tail_bound']), int(fx['features']), int(fx['hidden'])
+    sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=int(s)) for s in fx['seeds']]
+    comp = nf.CompositeTransform(_load_layers(nf, sds, D, H, K, Tb)).cuda().eval()
+    x = dev(fx['x'])
+    nf.set_matmul_dtype('bf16')
+    try:
+        with torch.no_grad():
+            y, ld = comp(x)
+            logp = nf.BaseNeuralSplineFlow(comp, nf.StandardNormal([D], device='cuda')).log_prob(x)
+            # ragged shapes through the bf16 kernel (K % 8 != 0 takes the scalar staging path)
+            g = torch.Generator().manual_seed(11)
+            for (B, Kin, N) in [(3, 5, 7), (130, 33, 129), (257, 784, 300)]:
+                W = torch.randn(N, Kin, generator=g) * 0.2
+                mask = (torch.rand(N, Kin, generator=g) > 0.4).float()
+                bias = torch.randn(N, generator=g)
+                xx = torch.randn(B, Kin, generator=g)
+                res = torch.randn(B, N, generator=g)
+                want = (torch.relu(xx).bfloat16().double() @ (W * mask).bfloat16().double().t()
+                        + bias.double() + res.double())
+                pl = nf._lib.PackedLinear(W.cuda(), mask.cuda(), bias.cuda(), nf._lib.NF_DTYPE_BF16)
+                got = nf._lib.masked_linear(xx.cuda(), pl, residual=res.cuda(), relu_in=True)
+                assert rel_err(got.cpu(), want) < 1e-4       # same bf16 operands, fp32 accumulation
+    finally:
+        nf.set_matmul_dtype('f32')
+    assert rel_err(logp.cpu(), fx['logp64']) < 2e-2            # the contract: log_prob within 2e-2
+    assert rel_err(ld.cpu(), fx['ld64']) < 2e-2
+    # outputs after 5 layers, element-wise: 99.9 % within 2e-2, the worst of the 25088 elements within 5e-2
+    e = ((y.cpu().double() - T(fx['y64'])).abs() / T(fx['y64']).abs().clamp_min(1.0)).reshape(-1)
+    assert torch.quantile(e, 0.999).item() < 2e-2 and e.max().item() < 5e-2
+    print('bf16 mode: log_prob rel err %.2e, y rel err %.2e' % (rel_err(logp.cpu(), fx['logp64']),
+                                                               rel_err(y.cpu(), fx['y64'])))
+
+
 # ------------------------------------------------------------------------------- affine / coupling
 def test_affine_ar_golden(nf):
     fx = load_golden('affine_ar')
