@@ -141,14 +141,17 @@ def main():
         # dominant kernel: the final MADE layer (512 -> 18032)
         final = flow._transform._transforms[0].autoregressive_net.final_layer
         nnz = float(final.mask.sum().item())
-        key = [k for k in kern if k[0] == 'masked_linear' and k[2] == final.out_features]
+        key = [k for k in kern if k[0] in ('made_rqs', 'masked_linear') and k[2] == final.out_features]
         if key:
+            fused = key[0][0] == 'made_rqs' 
             rows = key[0][3]
             n, ms = kern[key[0]]
             flop = 2.0 * nnz * rows
             peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
             ach = flop / (ms * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'masked_linear_%s_kernel (final layer 512->18032)' % args.dtype,
+            out['roofline'] = {'bound': 'mfma',
+                               'kernel': ('made_rqs_kernel<%s> (final layer 512->18032 fused with the spline)' if fused
+                                          else 'masked_linear_%s_kernel (final layer 512->18032)') % args.dtype,
                                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                                'traffic': None, 'launches': n, 'avg_launch_ms': ms, 'rows_per_launch': rows,
                                'algorithmic_flop_per_launch': flop,
@@ -161,7 +164,7 @@ def main():
             out['spline_kernel'] = {'bound': 'hbm', 'achieved': byts / (ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
                                     'unit': 'GB/s', 'frac': byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                     'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': byts}
-        out['kernel_ms'] = {'%s_%dx%d' % (k[0], k[1], k[2]): round(v[1], 4) for k, v in kern.items()}
+        out['kernel_ms'] = {'%s_%dx%d_rows%d' % (k[0], k[1], k[2], k[3]): round(v[1], 4) for k, v in kern.items()}
         if not args.no_cpu:
             n = min(args.cpu_sample, B)
             v, cores, err = cpu_baseline(sd_cpu, x[:n].cpu(), logp[:n].cpu(), reps=3)

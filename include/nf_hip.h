@@ -89,6 +89,33 @@ int nf_rqs_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index,
                double min_bin_width, double min_bin_height, double min_derivative,
                int inverse, void* stream);
 
+/* ---- final MADE layer fused with the spline: `params` never reaches HBM ---------------------------
+ *      (replaces made.py:358 `self.final_layer(outputs)` + transforms.py:819-860 `_elementwise` +
+ *       rational_quadratic.py:13-149 in one launch; the forward AND the per-pass inverse of the
+ *       autoregressive transform, transforms.py:488-500, go through it) ------------------------------ */
+
+/* 1 if the fused kernel handles this spline shape (4 <= K <= 32); the hidden width must also be a
+ * multiple of 8.  Otherwise callers use nf_masked_linear_fwd + nf_rqs_fwd. */
+int nf_made_rqs_supported(int K, int tails);
+/* Column tiles (256 packed weight rows = 256/P whole features each) for `features` features. */
+int nf_made_rqs_tiles(int features, int K, int tails);
+size_t nf_made_rqs_packed_bytes(int features, int in, int K, int tails, int dtype);
+/* fp32 scratch for the per-tile logdet partial sums: tiles * B floats. */
+size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, int tails);
+/* Packs the final layer W[features*P, in] (mask folded, rows regrouped to whole features per tile),
+ * its K-tile table (2*tiles int32) and its bias (tiles*256 floats). */
+int nf_made_rqs_pack(const float* W, const float* mask, const float* bias, int features, int in, int K,
+                     int tails, int dtype, void* packed, int32_t* ktab, float* bias_packed, void* stream);
+/* y, logabsdet (and optionally bin_idx) of the spline whose parameters are h @ Wm^T + bias; semantics of
+ * x, y, logabsdet, accumulate, bin_idx, tails, tail_bound, min_* and inverse as in nf_rqs_fwd
+ * (no feat_index, pre_div = 1: the autoregressive path). */
+int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                    const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                    int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                    float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
+                    int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                    double min_derivative, int inverse, int dtype, void* stream);
+
 /* ---- affine transform (replaces transforms.py:328-347 coupling, :540-566 autoregressive) -------- */
 
 /* scale = sigmoid(u + 2) + 1e-3; forward y = scale*x + shift, inverse y = (x - shift)/scale;
@@ -97,6 +124,25 @@ int nf_affine_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_inde
                   const float* params, int64_t param_row_stride, int layout,
                   float* y, int64_t y_row_stride, float* logabsdet, int accumulate,
                   int64_t B, int D, int inverse, void* stream);
+
+/* ---- legacy Gaussian MAF layer, float64 (replaces models/flows.py:239-263 MaskedAutoregressiveFlow on
+ *      models/made.py:11-89 SimpleMADE; the reference runs this class in float64 only) ---------------- */
+
+/* folded = mask ? mask*W : W, elementwise over [out,in] (made.py:21 `self.mask * self.weight`, once). */
+int nf_fold_f64(const double* W, const double* mask, int out, int in, double* folded, void* stream);
+/* y = act(x @ folded^T + bias), act = ReLU when relu_out (made.py:20-21, :40-46). */
+int nf_linear_f64_fwd(const double* x, int64_t x_row_stride, const double* folded_w, const double* bias,
+                      double* y, int64_t y_row_stride, int64_t B, int in, int out, int relu_out, void* stream);
+/* made_out[b] = [mu (D) | logp (D)]; x = (z - mu)*exp(logp/2), features flipped when reverse_input;
+ * logJ[b] = sum(logp)/2 (flows.py:242-247). */
+int nf_maf_fwd(const double* z, int64_t z_row_stride, const double* made_out, int64_t out_row_stride,
+               double* x, int64_t x_row_stride, double* logJ, int64_t B, int D, int reverse_input, void* stream);
+/* One pass of reverse() (flows.py:255-261): z[:,dim] = mu[:,dim] + x'[:,dim]*exp(min(-logp[:,dim]/2, 10)), x' = x
+ * with features flipped back when reverse_input; when logJ != NULL also logJ[b] = sum_d min(-logp_d/2, 10)
+ * (the reference keeps the value of the LAST pass). */
+int nf_maf_reverse_step(const double* x, int64_t x_row_stride, const double* made_out, int64_t out_row_stride,
+                        double* z, int64_t z_row_stride, double* logJ, int64_t B, int D, int dim,
+                        int reverse_input, void* stream);
 
 #ifdef __cplusplus
 }

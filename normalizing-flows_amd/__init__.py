@@ -8,6 +8,7 @@ from .transforms import CompositeTransform, AutoregressiveTransform, MaskedAffin
     MaskedPiecewiseRationalQuadraticAutoregressiveTransform, CouplingTransform, AffineCouplingTransform, \
     PiecewiseRationalQuadraticCouplingTransform
 from . import parallel
+from .flows import MaskedAutoregressiveFlow, SimpleMADE, SimpleMaskedLinear
 from .distributions import Distribution, StandardNormal, BaseNeuralSplineFlow, Flow
 
 __all__ = [n for n in dir() if not n.startswith('_')]

@@ -39,6 +39,24 @@ _SIGNATURES = {
     'nf_affine_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
                                  _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_int,
                                  _c.c_int, _c.c_void_p]),
+    'nf_made_rqs_supported': (_c.c_int, [_c.c_int, _c.c_int]),
+    'nf_made_rqs_tiles': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
+    'nf_made_rqs_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'nf_made_rqs_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
+    'nf_made_rqs_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                    _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'nf_made_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                   _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                   _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                   _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_int,
+                                   _c.c_void_p]),
+    'nf_fold_f64': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    'nf_linear_f64_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                     _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_maf_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                              _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_maf_reverse_step': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                       _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -116,6 +134,66 @@ class PackedLinear:
         with torch.cuda.device(w.device):
             _check(lib.nf_made_pack(w.data_ptr(), _ptr(m), self.out, self.inp, dtype, self.packed.data_ptr(),
                                     self.ktab.data_ptr(), _stream()), 'nf_made_pack')
+
+
+class PackedFusedFinal:
+    """Device buffers of nf_made_rqs_pack: the final MADE layer regrouped to whole features per tile."""
+    __slots__ = ('features', 'inp', 'K', 'tails', 'dtype', 'packed', 'ktab', 'bias', 'tiles')
+
+    def __init__(self, weight, mask, bias, features, num_bins, tails, dtype=NF_DTYPE_F32):
+        lib = load()
+        w = _dev(weight.detach().contiguous(), 'weight')
+        m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
+        b = None if bias is None else _dev(bias.detach().contiguous(), 'bias')
+        t = 1 if tails == 'linear' else 0
+        self.features, self.inp, self.K, self.tails, self.dtype = int(features), int(w.shape[1]), int(num_bins), t, dtype
+        self.tiles = lib.nf_made_rqs_tiles(self.features, self.K, t)
+        if self.tiles == 0:
+            raise NfError(-2, 'nf_made_rqs_tiles')
+        self.packed = torch.empty(lib.nf_made_rqs_packed_bytes(self.features, self.inp, self.K, t, dtype),
+                                  dtype=torch.uint8, device=w.device)
+        self.ktab = torch.empty(2 * self.tiles, dtype=torch.int32, device=w.device)
+        self.bias = torch.empty(256 * self.tiles, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _check(lib.nf_made_rqs_pack(w.data_ptr(), _ptr(m), _ptr(b), self.features, self.inp, self.K, t, dtype,
+                                        self.packed.data_ptr(), self.ktab.data_ptr(), self.bias.data_ptr(),
+                                        _stream()), 'nf_made_rqs_pack')
+
+
+def made_rqs_supported(num_bins, tails, hidden):
+    return (tails in (None, 'linear') and hidden % 8 == 0
+            and load().nf_made_rqs_supported(int(num_bins), 1 if tails == 'linear' else 0) == 1)
+
+
+def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accumulate=False, min_bin_width=1e-3,
+             min_bin_height=1e-3, min_derivative=1e-3, want_bins=False):
+    """Fused final MADE layer + spline: h [B, hidden], x [B, features] -> (y, logabsdet[B], bins or None)."""
+    lib = load()
+    _dev(h, 'hidden')
+    _dev(x, 'inputs')
+    B = x.shape[0]
+    hp, hs = _rows(h, 'hidden')
+    xp, xs = _rows(x, 'inputs')
+    if h.shape[0] != B or h.shape[1] != pf.inp or x.shape[1] != pf.features:
+        raise ValueError('Expected hidden [B,%d] and inputs [B,%d]' % (pf.inp, pf.features))
+    if out is None:
+        out = torch.empty_like(x)
+    yp, ys = _rows(out, 'outputs')
+    if logabsdet is None:
+        logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        accumulate = False
+    bins = torch.empty((B, pf.features), dtype=torch.int32, device=x.device) if want_bins else None
+    ws = torch.empty(max(1, pf.tiles * B), dtype=torch.float32, device=x.device)
+
+    def launch():
+        return lib.nf_made_rqs_fwd(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs, yp, ys,
+                                   logabsdet.data_ptr(), int(accumulate), _ptr(bins), ws.data_ptr(), ws.numel() * 4, B,
+                                   pf.inp, pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
+                                   float(min_bin_height), float(min_derivative), int(inverse), pf.dtype, _stream())
+    with torch.cuda.device(x.device):
+        code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * (3 * pf.K - 1), B), launch)
+        _check(code, 'nf_made_rqs_fwd')
+    return out, logabsdet, bins
 
 
 def masked_linear(x, pl, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False, out=None):
@@ -217,3 +295,56 @@ _timer = None
 def set_timer(t):
     global _timer
     _timer = t
+
+
+# ------------------------------------------------------------------------------------------------ fp64 MAF
+def fold_f64(weight, mask):
+    lib = load()
+    w = _dev(weight.detach().contiguous(), 'weight', torch.float64)
+    m = None if mask is None else _dev(mask.detach().to(torch.float64).contiguous(), 'mask', torch.float64)
+    out = torch.empty_like(w)
+    with torch.cuda.device(w.device):
+        _check(lib.nf_fold_f64(w.data_ptr(), _ptr(m), w.shape[0], w.shape[1], out.data_ptr(), _stream()), 'nf_fold_f64')
+    return out
+
+
+def linear_f64(x, folded, bias, relu_out=False):
+    lib = load()
+    _dev(x, 'x', torch.float64)
+    xp, xs = _rows(x, 'x')
+    B = x.shape[0]
+    if x.shape[1] != folded.shape[1]:
+        raise ValueError('Expected %d input features, got %d' % (folded.shape[1], x.shape[1]))
+    y = torch.empty((B, folded.shape[0]), dtype=torch.float64, device=x.device)
+    yp, ys = _rows(y, 'y')
+    b = None if bias is None else _dev(bias.detach().contiguous(), 'bias', torch.float64)
+    with torch.cuda.device(x.device):
+        _check(lib.nf_linear_f64_fwd(xp, xs, folded.data_ptr(), _ptr(b), yp, ys, B, folded.shape[1], folded.shape[0],
+                                     int(relu_out), _stream()), 'nf_linear_f64_fwd')
+    return y
+
+
+def maf_fwd(z, made_out, reverse_input):
+    lib = load()
+    _dev(z, 'z', torch.float64)
+    B, D = z.shape
+    zp, zs = _rows(z, 'z')
+    op, os_ = _rows(_dev(made_out, 'made_out', torch.float64), 'made_out')
+    x = torch.empty_like(z)
+    xp, xs = _rows(x, 'x')
+    logJ = torch.empty(B, dtype=torch.float64, device=z.device)
+    with torch.cuda.device(z.device):
+        _check(lib.nf_maf_fwd(zp, zs, op, os_, xp, xs, logJ.data_ptr(), B, D, int(bool(reverse_input)), _stream()),
+               'nf_maf_fwd')
+    return x, logJ
+
+
+def maf_reverse_step(x, made_out, z, dim, reverse_input, logJ=None):
+    lib = load()
+    B, D = x.shape
+    xp, xs = _rows(_dev(x, 'x', torch.float64), 'x')
+    op, os_ = _rows(_dev(made_out, 'made_out', torch.float64), 'made_out')
+    zp, zs = _rows(_dev(z, 'z', torch.float64), 'z')
+    with torch.cuda.device(x.device):
+        _check(lib.nf_maf_reverse_step(xp, xs, op, os_, zp, zs, _ptr(logJ), B, D, int(dim), int(bool(reverse_input)),
+                                       _stream()), 'nf_maf_reverse_step')

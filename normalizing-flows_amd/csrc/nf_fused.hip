@@ -1,0 +1,507 @@
+// Final MADE layer fused with the rational-quadratic spline (gfx950).
+//
+//   params[b, d*P + j] = h[b,:] . Wm[d*P + j, :] + bias      (models/made.py:150-152, :358)
+//   y[b,d], ld[b,d]    = RQ spline(x[b,d]; params[b, d*P .. d*P+P-1])   (transforms.py:819-860,
+//                                                                        rational_quadratic.py:13-149)
+//   logabsdet[b]       = sum_d ld[b,d]                                   (helper_functions.py:393-398)
+//
+// The reference materialises `params` ([B, D*P] floats: 72 KB per sample at D=784, K=8), the largest HBM
+// object of the whole path, only to consume it once.  Here a workgroup owns 128 samples x FPT features
+// (FPT = 256 / P whole features, 11 at P=23, so the 256-column weight tile holds only whole parameter
+// rows), accumulates the 128 x 256 tile on the matrix cores exactly like nf_gemm.hip, drops it into LDS
+// (aliasing the operand staging buffers), and evaluates the spline from there: `params` never reaches
+// HBM.  Per-sample logdet partial sums go to a [n_tiles, B] scratch (4 bytes per sample per tile) that a
+// second tiny kernel adds up in a fixed order - deterministic, no float atomics.
+//
+// 512 threads = 8 waves as 2 (rows) x 4 (cols), 64 x 64 outputs per wave (2x2 MFMA tiles), so the
+// register budget matches nf_gemm.hip; the spline's VALU work runs beside other waves' MFMAs.
+#include "nf_common.h"
+#include "nf_rqs_eval.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int FM = 128, FN = 256;       // block tile
+constexpr int FT = 512;                 // threads
+constexpr int BK = 32, LDA = BK + 4;    // fp32 staging: K tile and padded LDS row (floats)
+constexpr int BK16 = 64, LDA16 = BK16 + 8;
+constexpr int EP_LD = 257;              // epilogue tile row stride (floats): odd => conflict-free per-lane rows
+constexpr int GROUP_M = 8;
+
+struct FusedArgs {
+    const float* h;          // [M, K] conditioner hidden state
+    int64_t ldh;
+    const void* w;           // packed [n_tiles*256][kpad] (f32 or bf16)
+    int kpad;
+    const int32_t* ktab;     // [n_tiles][2] in 32-wide K tiles
+    const float* bias;       // packed [n_tiles*256]
+    const float* x;          // [M, D] transform inputs
+    int64_t ldx;
+    float* y;
+    int64_t ldy;
+    float* partial;          // [n_tiles][M]
+    int32_t* bins;           // nullable [M, D]
+    int64_t M;
+    int K, D;
+    int fpt;                 // features per tile
+    int n_tiles;             // column tiles computed by this launch, starting at tn0 (window)
+    int tn0;
+    int feat_limit;          // features >= feat_limit are left untouched (incremental inverse); D = all
+    int64_t m_tiles;
+    RqsConst c;
+};
+
+__device__ __forceinline__ void tile_of_block(const FusedArgs& g, int64_t& tm, int& tn) {
+    const int64_t nwg = (int64_t)gridDim.x;
+    const int64_t bid = blockIdx.x;
+    const int64_t q = nwg / 8, r = nwg % 8;
+    const int64_t xcd = bid % 8;
+    const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    const int64_t per_group = (int64_t)GROUP_M * g.n_tiles;
+    const int64_t grp = wg / per_group;
+    const int64_t first_m = grp * GROUP_M;
+    const int64_t gm = min((int64_t)GROUP_M, g.m_tiles - first_m);
+    const int64_t in = wg - grp * per_group;
+    tm = first_m + in % gm;
+    tn = (int)(in / gm) + g.tn0;
+}
+
+// ---- operand staging (fp32 / bf16 flavours share the kernel skeleton through this trait) -------------
+template <bool BF16>
+struct Stage;
+
+template <>
+struct Stage<false> {
+    static constexpr int kBK = BK;
+    const float *a0, *a1, *b0, *b1, *b2, *b3;
+    float4 ra0, ra1, rb0, rb1, rb2, rb3;
+    float *as, *bs;
+    int skc, K;
+
+    __device__ __forceinline__ void init(const FusedArgs& g, char* lds, int64_t m0, int tn, int tid) {
+        const int srow = tid >> 3;
+        skc = (tid & 7) * 4;
+        K = g.K;
+        a0 = g.h + min(m0 + srow, g.M - 1) * g.ldh;
+        a1 = g.h + min(m0 + srow + 64, g.M - 1) * g.ldh;
+        b0 = (const float*)g.w + (int64_t)(tn * FN + srow) * g.kpad + skc;
+        b1 = b0 + (int64_t)64 * g.kpad;
+        b2 = b0 + (int64_t)128 * g.kpad;
+        b3 = b0 + (int64_t)192 * g.kpad;
+        as = (float*)lds + srow * LDA + skc;
+        bs = (float*)lds + FM * LDA + srow * LDA + skc;
+    }
+    __device__ __forceinline__ float4 lda(const float* p, int k) const {
+        return *reinterpret_cast<const float4*>(p + min(k, K - 4));      // K % 8 == 0, rows 16-byte aligned
+    }
+    __device__ __forceinline__ void load(int kt) {
+        const int k = kt * BK + skc;
+        ra0 = lda(a0, k);
+        ra1 = lda(a1, k);
+        rb0 = *reinterpret_cast<const float4*>(b0 + kt * BK);
+        rb1 = *reinterpret_cast<const float4*>(b1 + kt * BK);
+        rb2 = *reinterpret_cast<const float4*>(b2 + kt * BK);
+        rb3 = *reinterpret_cast<const float4*>(b3 + kt * BK);
+    }
+    __device__ __forceinline__ float4 tail(float4 a, int k) const {
+        a.x = k < K ? a.x : 0.f;
+        a.y = k + 1 < K ? a.y : 0.f;
+        a.z = k + 2 < K ? a.z : 0.f;
+        a.w = k + 3 < K ? a.w : 0.f;
+        return a;
+    }
+    __device__ __forceinline__ void store(int kt) {
+        const int k = kt * BK + skc;
+        *reinterpret_cast<float4*>(as) = tail(ra0, k);
+        *reinterpret_cast<float4*>(as + 64 * LDA) = tail(ra1, k);
+        *reinterpret_cast<float4*>(bs) = rb0;
+        *reinterpret_cast<float4*>(bs + 64 * LDA) = rb1;
+        *reinterpret_cast<float4*>(bs + 128 * LDA) = rb2;
+        *reinterpret_cast<float4*>(bs + 192 * LDA) = rb3;
+    }
+    // 64 MFMAs (32x32x2 f32) on the staged tile: within an 8-wide K chunk lanes 0-31 own k 0..3 and lanes
+    // 32-63 own k 4..7 of both operands (a reordering of the K sum).
+    __device__ __forceinline__ void mma(const char* lds, int wr, int wc, int lane, f32x16 (&acc)[2][2]) const {
+        const float* As = (const float*)lds;
+        const float* Bs = As + FM * LDA;
+        const int frow = lane & 31, fk = (lane >> 5) * 4;
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4*>(&As[(wr * 64 + i * 32 + frow) * LDA + kc * 8 + fk]);
+                b[i] = *reinterpret_cast<const float4*>(&Bs[(wc * 64 + i * 32 + frow) * LDA + kc * 8 + fk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+};
+
+template <>
+struct Stage<true> {
+    static constexpr int kBK = BK16;
+    // 16-byte (8 x bf16) chunks: A 128 rows x 8 chunks = 1024 -> 2 per thread, B 256 x 8 = 2048 -> 4 per thread
+    const float *a0, *a1;
+    const __bf16 *b0, *b1, *b2, *b3;
+    float4 ra0l, ra0h, ra1l, ra1h;
+    bf16x8 rb0, rb1, rb2, rb3;
+    __bf16 *as, *bs;
+    int skc, K;
+
+    __device__ __forceinline__ void init(const FusedArgs& g, char* lds, int64_t m0, int tn, int tid) {
+        const int srow = tid >> 3;
+        skc = (tid & 7) * 8;
+        K = g.K;
+        a0 = g.h + min(m0 + srow, g.M - 1) * g.ldh;
+        a1 = g.h + min(m0 + srow + 64, g.M - 1) * g.ldh;
+        b0 = (const __bf16*)g.w + (int64_t)(tn * FN + srow) * g.kpad + skc;
+        b1 = b0 + (int64_t)64 * g.kpad;
+        b2 = b0 + (int64_t)128 * g.kpad;
+        b3 = b0 + (int64_t)192 * g.kpad;
+        as = (__bf16*)lds + srow * LDA16 + skc;
+        bs = (__bf16*)lds + FM * LDA16 + srow * LDA16 + skc;
+    }
+    __device__ __forceinline__ void lda(const float* p, int k, float4& lo, float4& hi) const {
+        const int kk = min(k, K - 8);
+        lo = *reinterpret_cast<const float4*>(p + kk);
+        hi = *reinterpret_cast<const float4*>(p + kk + 4);
+    }
+    __device__ __forceinline__ void load(int kt) {
+        const int k = kt * BK16 + skc;
+        lda(a0, k, ra0l, ra0h);
+        lda(a1, k, ra1l, ra1h);
+        rb0 = *reinterpret_cast<const bf16x8*>(b0 + kt * BK16);
+        rb1 = *reinterpret_cast<const bf16x8*>(b1 + kt * BK16);
+        rb2 = *reinterpret_cast<const bf16x8*>(b2 + kt * BK16);
+        rb3 = *reinterpret_cast<const bf16x8*>(b3 + kt * BK16);
+    }
+    __device__ __forceinline__ bf16x8 cvt(float4 lo, float4 hi, int k) const {
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(k + j < K ? v[j] : 0.f);
+        return o;
+    }
+    __device__ __forceinline__ void store(int kt) {
+        const int k = kt * BK16 + skc;
+        *reinterpret_cast<bf16x8*>(as) = cvt(ra0l, ra0h, k);
+        *reinterpret_cast<bf16x8*>(as + 64 * LDA16) = cvt(ra1l, ra1h, k);
+        *reinterpret_cast<bf16x8*>(bs) = rb0;
+        *reinterpret_cast<bf16x8*>(bs + 64 * LDA16) = rb1;
+        *reinterpret_cast<bf16x8*>(bs + 128 * LDA16) = rb2;
+        *reinterpret_cast<bf16x8*>(bs + 192 * LDA16) = rb3;
+    }
+    __device__ __forceinline__ void mma(const char* lds, int wr, int wc, int lane, f32x16 (&acc)[2][2]) const {
+        const __bf16* As = (const __bf16*)lds;
+        const __bf16* Bs = As + FM * LDA16;
+        const int frow = lane & 31, fk = (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[(wr * 64 + i * 32 + frow) * LDA16 + ks * 16 + fk]);
+                b[i] = *reinterpret_cast<const bf16x8*>(&Bs[(wc * 64 + i * 32 + frow) * LDA16 + ks * 16 + fk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+template <bool BF16, int KT, bool INV>
+__global__ __launch_bounds__(FT, 2) void made_rqs_kernel(const FusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // [0, 64*EP_LD*4): operand staging during the K loop, then the epilogue parameter tile
+    float* tile = (float*)lds;
+    float* xs = tile + 64 * EP_LD;                   // [128][fpt] inputs, overwritten by outputs
+    float* ldp = xs + FM * g.fpt;                    // [64][fpt] per-element logdets of one half
+
+    int64_t tm;
+    int tn;
+    tile_of_block(g, tm, tn);
+    const int64_t m0 = tm * FM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fpt = g.fpt, P = g.c.P;
+    const int f0 = tn * fpt;
+    const int fv = min(fpt, g.feat_limit - f0);      // features of this tile to evaluate (>= 1 by construction)
+
+    // inputs of the tile: consecutive threads take consecutive features of a row
+    for (int i = tid; i < FM * fpt; i += FT) {
+        const int r = i / fpt, f = i - r * fpt;
+        float v = 0.f;
+        if (m0 + r < g.M && f < fv) v = g.x[(m0 + r) * g.ldx + f0 + f];
+        xs[i] = v;
+    }
+
+    const int kq = Stage<BF16>::kBK / 32;
+    const int kt_begin = g.ktab[2 * tn] / kq, kt_end = (g.ktab[2 * tn + 1] + kq - 1) / kq;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    Stage<BF16> st;
+    st.init(g, lds, m0, tn, tid);
+    if (kt_begin < kt_end) st.load(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();
+        st.store(kt);
+        __syncthreads();
+        st.load(min(kt + 1, kt_end - 1));            // prefetch under the MFMAs (last one is a re-read)
+        __builtin_amdgcn_sched_barrier(0);
+        st.mma(lds, wr, wc, lane, acc);
+    }
+
+    // ---- epilogue: two halves of 64 rows through the LDS tile ---------------------------------------
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                             // staging / previous half fully consumed
+        if (wr == half) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wc * 64 + j * 32 + (lane & 31);
+                const float bv = g.bias[tn * FN + col];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        tile[row * EP_LD + col] = acc[i][j][r] + bv;
+                    }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 64 * fv; e += FT) {
+            const int f = e >> 6, row = e & 63;
+            const int r = half * 64 + row;
+            float yv, ld;
+            int bin;
+            rqs_eval<KT, INV>(tile + row * EP_LD + f * P, xs[r * fpt + f], g.c, yv, ld, bin);
+            xs[r * fpt + f] = yv;
+            ldp[row * fpt + f] = ld;
+            if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + f] = bin;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f;
+            for (int f = 0; f < fv; ++f) s += ldp[tid * fpt + f];
+            const int64_t r = m0 + half * 64 + tid;
+            if (r < g.M) g.partial[(int64_t)tn * g.M + r] = s;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < FM * fpt; i += FT) {
+        const int r = i / fpt, f = i - r * fpt;
+        if (m0 + r < g.M && f < fv) g.y[(m0 + r) * g.ldy + f0 + f] = xs[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ partial, int n_tiles, int64_t M,
+                                                     float* __restrict__ lad, int accumulate) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    float s = 0.f;
+    for (int t = 0; t < n_tiles; ++t) s += partial[(int64_t)t * M + r];    // fixed order: deterministic
+    lad[r] = accumulate ? lad[r] + s : s;
+}
+
+// dst row pr of the packed matrix = src row tn*src_rows + j for j < src_rows (and in range), else zero
+template <typename T>
+__global__ void pack_fused_kernel(const float* __restrict__ W, const float* __restrict__ mask,
+                                  const float* __restrict__ bias, int out, int in, int src_rows, int kpad,
+                                  int64_t total, T* __restrict__ packed, float* __restrict__ bias_packed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pr = i / kpad;
+        const int k = (int)(i - pr * kpad);
+        const int tn = (int)(pr / FN), j = (int)(pr % FN);
+        const int64_t n = (int64_t)tn * src_rows + j;
+        const bool live = j < src_rows && n < out;
+        float v = 0.0f;
+        if (live && k < in) {
+            v = W[n * in + k];
+            if (mask) v *= mask[n * in + k];
+        }
+        packed[i] = (T)v;
+        if (k == 0) bias_packed[pr] = (live && bias) ? bias[n] : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict__ mask, int out, int in,
+                                                         int src_rows, int32_t* __restrict__ ktab) {
+    __shared__ int lo, hi;
+    const int tn = blockIdx.x;
+    if (threadIdx.x == 0) { lo = 0x7fffffff; hi = -1; }
+    __syncthreads();
+    int mylo = 0x7fffffff, myhi = -1;
+    const int row0 = tn * src_rows;
+    const int rows = min(src_rows, out - row0);
+    if (mask) {
+        for (int64_t i = threadIdx.x; i < (int64_t)rows * in; i += blockDim.x) {
+            const int r = (int)(i / in), k = (int)(i - (int64_t)r * in);
+            if (mask[(int64_t)(row0 + r) * in + k] != 0.0f) { mylo = min(mylo, k); myhi = max(myhi, k); }
+        }
+    } else if (rows > 0) {
+        mylo = 0;
+        myhi = in - 1;
+    }
+    atomicMin(&lo, mylo);
+    atomicMax(&hi, myhi);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (hi < 0) { ktab[2 * tn] = 0; ktab[2 * tn + 1] = 0; }
+        else { ktab[2 * tn] = lo / 32; ktab[2 * tn + 1] = hi / 32 + 1; }
+    }
+}
+
+inline int kpad_of(int in) { return (in + BK16 - 1) / BK16 * BK16; }
+inline int fpt_of(int P) { return FN / P; }
+inline bool fused_supported(int K, int tails) {   // (and the hidden width must be a multiple of 8)
+    const int P = tails ? 3 * K - 1 : 3 * K + 1;
+    return K >= 4 && K <= 32 && P <= FN;
+}
+inline size_t lds_bytes(int fpt) { return sizeof(float) * ((size_t)64 * EP_LD + (size_t)FM * fpt + (size_t)64 * fpt); }
+
+template <bool BF16, int KT, bool INV>
+int launch_one(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;          // raise the dynamic-LDS cap once per instantiation (not an allocation)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)made_rqs_kernel<BF16, KT, INV>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((made_rqs_kernel<BF16, KT, INV>), dim3(grid), dim3(FT), lds, s, g);
+    return nf_launch_status();
+}
+
+template <bool BF16, bool INV>
+int launch_k(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+    switch (g.c.K) {
+        case 4: return launch_one<BF16, 4, INV>(g, grid, lds, s);
+        case 8: return launch_one<BF16, 8, INV>(g, grid, lds, s);
+        case 10: return launch_one<BF16, 10, INV>(g, grid, lds, s);
+        case 16: return launch_one<BF16, 16, INV>(g, grid, lds, s);
+        default: return launch_one<BF16, 0, INV>(g, grid, lds, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int nf_made_rqs_supported(int K, int tails) { return fused_supported(K, tails) ? 1 : 0; }
+
+extern "C" int nf_made_rqs_tiles(int features, int K, int tails) {
+    if (!fused_supported(K, tails) || features <= 0) return 0;
+    const int fpt = fpt_of(tails ? 3 * K - 1 : 3 * K + 1);
+    return (features + fpt - 1) / fpt;
+}
+
+extern "C" size_t nf_made_rqs_packed_bytes(int features, int in, int K, int tails, int dtype) {
+    const int nt = nf_made_rqs_tiles(features, K, tails);
+    if (nt == 0 || in <= 0) return 0;
+    return (size_t)nt * FN * kpad_of(in) * (dtype == NF_DTYPE_BF16 ? 2 : 4);
+}
+
+extern "C" size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, int tails) {
+    const int nt = nf_made_rqs_tiles(features, K, tails);
+    return nt == 0 || B <= 0 ? 0 : sizeof(float) * (size_t)nt * (size_t)B;
+}
+
+extern "C" int nf_made_rqs_pack(const float* W, const float* mask, const float* bias, int features, int in, int K,
+                                int tails, int dtype, void* packed, int32_t* ktab, float* bias_packed, void* stream) {
+    if (!W || !packed || !ktab || !bias_packed) return NF_ERR_NULL;
+    if (features <= 0 || in <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
+    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
+    const int P = tails ? 3 * K - 1 : 3 * K + 1;
+    const int fpt = fpt_of(P), nt = (features + fpt - 1) / fpt, out = features * P, kpad = kpad_of(in);
+    const int64_t total = (int64_t)nt * FN * kpad;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == NF_DTYPE_F32)
+        hipLaunchKernelGGL(pack_fused_kernel<float>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
+                           total, (float*)packed, bias_packed);
+    else
+        hipLaunchKernelGGL(pack_fused_kernel<__bf16>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
+                           total, (__bf16*)packed, bias_packed);
+    hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, fpt * P, ktab);
+    return nf_launch_status();
+}
+
+extern "C" int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                                     const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                                     int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                                     float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
+                                     int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                                     double min_derivative, int inverse, int dtype, int tile_begin, int tile_count,
+                                     int feat_limit, int reduce, void* stream) {
+    if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
+    if (B == 0) return NF_OK;
+    if (!h || !packed_w || !ktab || !bias_packed || !x || !y || !logabsdet || !workspace) return NF_ERR_NULL;
+    if (h_row_stride < in || x_row_stride < features || y_row_stride < features) return NF_ERR_LAYOUT;
+    // the hidden state is staged with 16-byte loads only (it comes from nf_masked_linear_fwd)
+    if (in % 8 != 0 || h_row_stride % 4 != 0 || ((uintptr_t)h & 15) != 0) return NF_ERR_LAYOUT;
+    if (workspace_bytes < nf_made_rqs_workspace_bytes(B, features, K, tails)) return NF_ERR_SCRATCH;
+
+    FusedArgs g;
+    g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
+    g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx;
+    g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
+    const int all_tiles = (features + g.fpt - 1) / g.fpt;
+    if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
+    if (feat_limit > features || (tile_count > 0 && feat_limit <= (tile_begin + tile_count - 1) * g.fpt)) return NF_ERR_SHAPE;
+    g.n_tiles = tile_count;
+    g.tn0 = tile_begin;
+    g.feat_limit = feat_limit;
+    g.m_tiles = (B + FM - 1) / FM;
+    const int64_t grid = g.m_tiles * g.n_tiles;
+    if (grid > 0x7fffffff) return NF_ERR_SHAPE;
+    const size_t lds = lds_bytes(g.fpt);
+    if (lds > 160 * 1024) return NF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = NF_OK;
+    if (grid > 0) {
+        if (dtype == NF_DTYPE_BF16)
+            rc = inverse ? launch_k<true, true>(g, (int)grid, lds, s) : launch_k<true, false>(g, (int)grid, lds, s);
+        else
+            rc = inverse ? launch_k<false, true>(g, (int)grid, lds, s) : launch_k<false, false>(g, (int)grid, lds, s);
+    }
+    if (rc != NF_OK || !reduce) return rc;
+    hipLaunchKernelGGL(rowsum_kernel, dim3(nf_ceil_div(B, 256)), dim3(256), 0, s, workspace, all_tiles, B, logabsdet,
+                       accumulate);
+    return nf_launch_status();
+}
+
+extern "C" int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                               const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                               int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                               float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
+                               int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                               double min_derivative, int inverse, int dtype, void* stream) {
+    return nf_made_rqs_fwd_tiles(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride,
+                                 logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
+                                 tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
+                                 nf_made_rqs_tiles(features, K, tails), features, 1, stream);
+}

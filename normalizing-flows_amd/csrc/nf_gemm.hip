@@ -41,7 +41,8 @@ struct GemmArgs {
     int64_t M;
     int N, K;
     int relu_in, relu_out;
-    int n_tiles;
+    int n_tiles;             // column tiles computed by this launch ...
+    int tn0;                 // ... starting at this one (tile window; 0 / all for a full layer)
     int64_t m_tiles;
     int vec_a;               // x rows 16-byte aligned and K % 4 == 0
 };
@@ -61,7 +62,7 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int64_t& tm, in
     const int64_t gm = min((int64_t)GROUP_M, g.m_tiles - first_m);
     const int64_t in = wg - grp * per_group;
     tm = first_m + in % gm;
-    tn = (int)(in / gm);
+    tn = (int)(in / gm) + g.tn0;
 }
 
 // load_one only issues the loads; everything that consumes a loaded value lives in store_one so that
@@ -459,10 +460,11 @@ extern "C" int nf_made_pack(const float* W, const float* mask, int out, int in, 
     return nf_launch_status();
 }
 
-extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const void* packed_w, const int32_t* ktab,
-                                    const float* bias, const float* residual, int64_t residual_row_stride,
-                                    const float* in_scale, const float* in_shift, float* y, int64_t y_row_stride,
-                                    int64_t B, int in, int out, int relu_in, int relu_out, int dtype, void* stream) {
+extern "C" int nf_masked_linear_fwd_tiles(const float* x, int64_t x_row_stride, const void* packed_w,
+                                          const int32_t* ktab, const float* bias, const float* residual,
+                                          int64_t residual_row_stride, const float* in_scale, const float* in_shift,
+                                          float* y, int64_t y_row_stride, int64_t B, int in, int out, int relu_in,
+                                          int relu_out, int dtype, int n_tile_begin, int n_tile_count, void* stream) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (B == 0) return NF_OK;
     if (!x || !packed_w || !ktab || !y) return NF_ERR_NULL;
@@ -473,7 +475,10 @@ extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const 
     g.x = x; g.ldx = x_row_stride; g.w = (const float*)packed_w; g.kpad = kpad_of(in); g.ktab = ktab;
     g.bias = bias; g.res = residual; g.ldr = residual_row_stride; g.in_scale = in_scale; g.in_shift = in_shift;
     g.y = y; g.ldy = y_row_stride; g.M = B; g.N = out; g.K = in; g.relu_in = relu_in; g.relu_out = relu_out;
-    g.n_tiles = n_tiles_of(out);
+    if (n_tile_begin < 0 || n_tile_count < 0 || n_tile_begin + n_tile_count > n_tiles_of(out)) return NF_ERR_SHAPE;
+    if (n_tile_count == 0) return NF_OK;
+    g.n_tiles = n_tile_count;
+    g.tn0 = n_tile_begin;
     g.m_tiles = (B + BM - 1) / BM;
     const int vec = dtype == NF_DTYPE_BF16 ? 8 : 4;      // floats per staged chunk
     g.vec_a = (in % vec == 0) && (x_row_stride % 4 == 0) && (((uintptr_t)x & 15) == 0);
@@ -506,4 +511,13 @@ extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const 
         default: hipLaunchKernelGGL((masked_linear_f32_kernel<true, true, true>), gr, bl, 0, s, g); break;
     }
     return nf_launch_status();
+}
+
+extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const void* packed_w, const int32_t* ktab,
+                                    const float* bias, const float* residual, int64_t residual_row_stride,
+                                    const float* in_scale, const float* in_shift, float* y, int64_t y_row_stride,
+                                    int64_t B, int in, int out, int relu_in, int relu_out, int dtype, void* stream) {
+    return nf_masked_linear_fwd_tiles(x, x_row_stride, packed_w, ktab, bias, residual, residual_row_stride, in_scale,
+                                      in_shift, y, y_row_stride, B, in, out, relu_in, relu_out, dtype, 0,
+                                      out > 0 ? n_tiles_of(out) : 0, stream);
 }

@@ -64,6 +64,18 @@ class _PackedMixin:
             cached = self._pack_cache
         return cached[1]
 
+    def _packed_fused_final(self, features, num_bins, tails):
+        """Final layer regrouped for the fused GEMM + spline kernel (nf_made_rqs_pack), cached likewise."""
+        key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
+               get_matmul_dtype(), self.weight.device, features, num_bins, tails)
+        cached = getattr(self, '_fused_cache', None)
+        if cached is None or cached[0] != key:
+            pf = _lib.PackedFusedFinal(self.weight, getattr(self, 'mask', None), self.bias, features, num_bins, tails,
+                                       _MATMUL_DTYPE[get_matmul_dtype()])
+            object.__setattr__(self, '_fused_cache', (key, pf))
+            cached = self._fused_cache
+        return cached[1]
+
     def fused(self, x, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False):
         _require_inference(self)
         return _lib.masked_linear(x, self._packed_linear(), residual=residual, in_scale=in_scale,
@@ -217,11 +229,15 @@ class MADE(nn.Module):
         self.blocks = nn.ModuleList(blocks)
         self.final_layer = MaskedLinear(prev, features * output_multiplier, features, random_mask, is_output=True)
 
-    def forward(self, inputs, context=None):
+    def forward_hidden(self, inputs, context=None):
+        """Everything up to (not including) the final layer: [B, hidden_features]."""
         if context is None:
             outputs = self.initial_layer.fused(inputs)
         else:
             outputs = self.initial_layer.fused(inputs, residual=self.context_layer(context))
         for block in self.blocks:
             outputs = block(outputs, context)
-        return self.final_layer.fused(outputs)
+        return outputs
+
+    def forward(self, inputs, context=None):
+        return self.final_layer.fused(self.forward_hidden(inputs, context))

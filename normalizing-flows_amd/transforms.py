@@ -76,8 +76,7 @@ class AutoregressiveTransform(nn.Module):
         for s in range(0, max(B, 1), CHUNK_ROWS):
             e = min(B, s + CHUNK_ROWS)
             ctx = None if context is None else context[s:e]
-            params = self.autoregressive_net(inputs[s:e], ctx)
-            self._elementwise(inputs[s:e], params, outputs[s:e], logabsdet[s:e], inverse=False)
+            self._transform_rows(inputs[s:e], inputs[s:e], ctx, outputs[s:e], logabsdet[s:e], inverse=False)
         return outputs, logabsdet
 
     def inverse(self, inputs, context=None):
@@ -91,12 +90,16 @@ class AutoregressiveTransform(nn.Module):
             cur = outputs[s:e]
             nxt = torch.empty_like(cur)
             for _ in range(D):
-                params = self.autoregressive_net(cur, ctx)
-                self._elementwise(inputs[s:e], params, nxt, logabsdet[s:e], inverse=True)
+                self._transform_rows(cur, inputs[s:e], ctx, nxt, logabsdet[s:e], inverse=True)
                 cur, nxt = nxt, cur
             if cur.data_ptr() != outputs[s:e].data_ptr():
                 outputs[s:e].copy_(cur)
         return outputs, logabsdet
+
+    def _transform_rows(self, net_inputs, inputs, context, outputs, logabsdet, inverse):
+        """Conditioner on `net_inputs`, elementwise transform of `inputs` into outputs / logabsdet."""
+        params = self.autoregressive_net(net_inputs, context)
+        self._elementwise(inputs, params, outputs, logabsdet, inverse)
 
     def _output_dim_multiplier(self):
         raise NotImplementedError()
@@ -162,12 +165,29 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
                         min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
                         want_bins=want_bins)
 
+    def _fusable(self):
+        net = self.autoregressive_net
+        return _lib.made_rqs_supported(self.num_bins, self.tails, net.final_layer.in_features)
+
+    def _transform_rows(self, net_inputs, inputs, context, outputs, logabsdet, inverse, want_bins=False):
+        """One launch for the final MADE layer and the spline (nf_made_rqs_fwd): the [B, D*P] parameter
+        tensor of the reference is never written.  Spline shapes the fused kernel does not cover
+        (K < 4, hidden width not a multiple of 8) take the two-kernel route."""
+        net = self.autoregressive_net
+        if not self._fusable():
+            params = net(net_inputs, context)
+            return self._elementwise(inputs, params, outputs, logabsdet, inverse, want_bins=want_bins)
+        hidden = net.forward_hidden(net_inputs, context)
+        made_module._require_inference(net.final_layer)
+        pf = net.final_layer._packed_fused_final(net.initial_layer.in_features, self.num_bins, self.tails)
+        return _lib.made_rqs(hidden, pf, inputs, self.tail_bound, inverse=inverse, out=outputs, logabsdet=logabsdet,
+                             min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                             min_derivative=self.min_derivative, want_bins=want_bins)
+
     def forward_with_bins(self, inputs, context=None):
         """forward() that also returns the int32 bin index of every element (-1 in the tails): the
         searchsorted result (helper_functions.py:507-512) that parity tests compare bit for bit."""
-        params = self.autoregressive_net(inputs, context)
-        y, lad, bins = self._elementwise(inputs, params, torch.empty_like(inputs), None, False, want_bins=True)
-        return y, lad, bins
+        return self._transform_rows(inputs, inputs, context, torch.empty_like(inputs), None, False, want_bins=True)
 
 
 # ------------------------------------------------------------------------------------ coupling

@@ -397,3 +397,36 @@ def test_module_errors(nf):
         t(torch.zeros(3, 6, device='cuda'))
     with pytest.raises(ValueError):
         nf.MADE(4, 8, random_mask=True)                      # made.py:305-306
+
+
+# ------------------------------------------------------------------------------- legacy MAF (config 1)
+@pytest.mark.parametrize('D', [2, 5])
+def test_maf_legacy_fp64_golden(nf, D):
+    """5 stacked MaskedAutoregressiveFlow layers in float64 with the reference's weights AND masks (the
+    masks are not in its state_dict).  forward/reverse reproduce the reference's numbers per layer;
+    reverse is deliberately not asserted to invert forward."""
+    fx = load_golden('maf_D%d' % D)
+    L = int(fx['n_layers'])
+    layers = []
+    for j in range(L):
+        f = nf.MaskedAutoregressiveFlow(D, [64], reverse_input=bool(fx['l%d/reverse_input' % j]))
+        sd = {}
+        n = sum(1 for k in fx if k.startswith('l%d/w' % j))
+        for i in range(n):
+            sd['made.model.%d.weight' % (2 * i)] = T(fx['l%d/w%d' % (j, i)])
+            sd['made.model.%d.bias' % (2 * i)] = T(fx['l%d/b%d' % (j, i)])
+        f.load_reference(sd, [T(fx['l%d/m%d' % (j, i)]) for i in range(n)])
+        layers.append(f.cuda().eval())
+    h = dev(fx['z'])
+    tot = torch.zeros(h.shape[0], dtype=torch.float64, device='cuda')
+    with torch.no_grad():
+        for j, f in enumerate(layers):
+            h, lj = f.forward(h)
+            assert h.dtype == torch.float64
+            assert rel_err(h.cpu(), fx['l%d/fwd_x' % j]) < 1e-12 and rel_err(lj.cpu(), fx['l%d/fwd_logJ' % j]) < 1e-12
+            tot += lj
+        assert rel_err(tot.cpu(), fx['logJ']) < 1e-12
+        r = dev(fx['x'])
+        for j in reversed(range(L)):
+            r, lj = layers[j].reverse(r)
+            assert rel_err(r.cpu(), fx['l%d/rev_z' % j]) < 1e-11 and rel_err(lj.cpu(), fx['l%d/rev_logJ' % j]) < 1e-11
