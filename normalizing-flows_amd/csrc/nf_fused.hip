@@ -224,7 +224,7 @@ struct Stage<true> {
 };
 
 template <bool BF16, int KT, bool INV>
-__global__ __launch_bounds__(FT, 2) void made_rqs_kernel(const FusedArgs g) {
+__global__ __launch_bounds__(FT, 4) void made_rqs_kernel(const FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // [0, 64*EP_LD*4): operand staging during the K loop, then the epilogue parameter tile
     float* tile = (float*)lds;
