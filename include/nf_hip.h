@@ -67,6 +67,16 @@ int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const void* packe
                          const float* in_scale, const float* in_shift, float* y, int64_t y_row_stride,
                          int64_t B, int in, int out, int relu_in, int relu_out, int dtype, void* stream);
 
+/* Same, restricted to the 128-column output tiles [n_tile_begin, n_tile_begin + n_tile_count): other
+ * columns of y are left untouched.  Used by the incremental autoregressive inverse, where one pass only
+ * changes the hidden units whose degree equals the feature that just became final (the reference
+ * recomputes the whole network D times, transforms.py:493-500). */
+int nf_masked_linear_fwd_tiles(const float* x, int64_t x_row_stride, const void* packed_w, const int32_t* ktab,
+                               const float* bias, const float* residual, int64_t residual_row_stride,
+                               const float* in_scale, const float* in_shift, float* y, int64_t y_row_stride,
+                               int64_t B, int in, int out, int relu_in, int relu_out, int dtype,
+                               int n_tile_begin, int n_tile_count, void* stream);
+
 /* ---- rational-quadratic spline (replaces rational_quadratic.py:13-149, helper_functions.py
  *      searchsorted :507-512 and sum_except_batch :393-398; callers transforms.py:212-247, 819-860) -- */
 
@@ -115,6 +125,17 @@ int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, 
                     float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
                     int tails, double tail_bound, double min_bin_width, double min_bin_height,
                     double min_derivative, int inverse, int dtype, void* stream);
+
+/* Same, restricted to column tiles [tile_begin, tile_begin + tile_count) and to features < feat_limit
+ * (later features of the last tile are neither read nor written); the per-tile logdet partial sums stay
+ * in `workspace` between calls and logabsdet is only produced when `reduce` != 0 (the last pass). */
+int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                          const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                          int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                          float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
+                          int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                          double min_derivative, int inverse, int dtype, int tile_begin, int tile_count,
+                          int feat_limit, int reduce, void* stream);
 
 /* ---- affine transform (replaces transforms.py:328-347 coupling, :540-566 autoregressive) -------- */
 

@@ -32,6 +32,15 @@ _SIGNATURES = {
                                         _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                         _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                         _c.c_int, _c.c_void_p]),
+    'nf_masked_linear_fwd_tiles': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                              _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                              _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                              _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_made_rqs_fwd_tiles': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                         _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                         _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                         _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_int,
+                                         _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_double,
                               _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64,
                               _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
@@ -166,8 +175,10 @@ def made_rqs_supported(num_bins, tails, hidden):
 
 
 def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accumulate=False, min_bin_width=1e-3,
-             min_bin_height=1e-3, min_derivative=1e-3, want_bins=False):
-    """Fused final MADE layer + spline: h [B, hidden], x [B, features] -> (y, logabsdet[B], bins or None)."""
+             min_bin_height=1e-3, min_derivative=1e-3, want_bins=False, tiles=None, feat_limit=None, reduce=True,
+             workspace=None):
+    """Fused final MADE layer + spline: h [B, hidden], x [B, features] -> (y, logabsdet[B], bins or None).
+    `tiles=(begin, count)`, `feat_limit`, `reduce`, `workspace`: one pass of the incremental inverse."""
     lib = load()
     _dev(h, 'hidden')
     _dev(x, 'inputs')
@@ -183,20 +194,27 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
         logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
         accumulate = False
     bins = torch.empty((B, pf.features), dtype=torch.int32, device=x.device) if want_bins else None
-    ws = torch.empty(max(1, pf.tiles * B), dtype=torch.float32, device=x.device)
+    ws = workspace if workspace is not None else torch.empty(max(1, pf.tiles * B), dtype=torch.float32,
+                                                              device=x.device)
+    tb, tc = (0, pf.tiles) if tiles is None else tiles
+    fl = pf.features if feat_limit is None else feat_limit
 
     def launch():
-        return lib.nf_made_rqs_fwd(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs, yp, ys,
-                                   logabsdet.data_ptr(), int(accumulate), _ptr(bins), ws.data_ptr(), ws.numel() * 4, B,
-                                   pf.inp, pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
-                                   float(min_bin_height), float(min_derivative), int(inverse), pf.dtype, _stream())
+        return lib.nf_made_rqs_fwd_tiles(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs,
+                                         yp, ys, logabsdet.data_ptr(), int(accumulate), _ptr(bins), ws.data_ptr(),
+                                         ws.numel() * 4, B, pf.inp, pf.features, pf.K, pf.tails, float(tail_bound),
+                                         float(min_bin_width), float(min_bin_height), float(min_derivative),
+                                         int(inverse), pf.dtype, int(tb), int(tc), int(fl), int(bool(reduce)),
+                                         _stream())
     with torch.cuda.device(x.device):
         code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * (3 * pf.K - 1), B), launch)
         _check(code, 'nf_made_rqs_fwd')
     return out, logabsdet, bins
 
 
-def masked_linear(x, pl, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False, out=None):
+def masked_linear(x, pl, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False, out=None,
+                  tiles=None):
+    """`tiles=(begin, count)` restricts the launch to those 128-column output tiles of `out`."""
     lib = load()
     _dev(x, 'x')
     xp, xs = _rows(x, 'x')
@@ -207,10 +225,12 @@ def masked_linear(x, pl, residual=None, in_scale=None, in_shift=None, relu_in=Fa
         out = torch.empty((B, pl.out), dtype=torch.float32, device=x.device)
     yp, ys = _rows(out, 'out')
     rp, rs = (None, 0) if residual is None else _rows(_dev(residual, 'residual'), 'residual')
+    tb, tc = (0, (pl.out + 127) // 128) if tiles is None else tiles
+
     def launch():
-        return lib.nf_masked_linear_fwd(xp, xs, pl.packed.data_ptr(), pl.ktab.data_ptr(), _ptr(pl.bias), rp, rs,
-                                        _ptr(in_scale), _ptr(in_shift), yp, ys, B, pl.inp, pl.out,
-                                        int(relu_in), int(relu_out), pl.dtype, _stream())
+        return lib.nf_masked_linear_fwd_tiles(xp, xs, pl.packed.data_ptr(), pl.ktab.data_ptr(), _ptr(pl.bias), rp, rs,
+                                              _ptr(in_scale), _ptr(in_shift), yp, ys, B, pl.inp, pl.out,
+                                              int(relu_in), int(relu_out), pl.dtype, int(tb), int(tc), _stream())
     with torch.cuda.device(x.device):
         code = launch() if _timer is None else _timer.record(('masked_linear', pl.inp, pl.out, B), launch)
         _check(code, 'nf_masked_linear_fwd')

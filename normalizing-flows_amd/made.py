@@ -76,10 +76,25 @@ class _PackedMixin:
             cached = self._fused_cache
         return cached[1]
 
-    def fused(self, x, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False):
+    def fused(self, x, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False, out=None,
+              tiles=None):
         _require_inference(self)
         return _lib.masked_linear(x, self._packed_linear(), residual=residual, in_scale=in_scale,
-                                  in_shift=in_shift, relu_in=relu_in, relu_out=relu_out)
+                                  in_shift=in_shift, relu_in=relu_in, relu_out=relu_out, out=out, tiles=tiles)
+
+    def tiles_of_degree(self, degree):
+        """(first, count) of the 128-column output tiles that hold a unit of this MADE degree, or None."""
+        cache = getattr(self, '_degree_tiles', None)
+        if cache is None:
+            cache = {}
+            deg = self.degrees.cpu().tolist()
+            for unit, d in enumerate(deg):
+                t = unit // 128
+                lo, hi = cache.get(d, (t, t))
+                cache[d] = (min(lo, t), max(hi, t))
+            object.__setattr__(self, '_degree_tiles', cache)
+        span = cache.get(int(degree))
+        return None if span is None else (span[0], span[1] - span[0] + 1)
 
 
 class DenseLinear(_PackedMixin, nn.Linear):
@@ -238,6 +253,46 @@ class MADE(nn.Module):
         for block in self.blocks:
             outputs = block(outputs, context)
         return outputs
+
+    # ---- incremental evaluation (autoregressive inverse) --------------------------------------------------
+    def hidden_program(self):
+        """The hidden stack as a list of fused-layer steps over named buffers, for evaluating it
+        tile window by tile window: (layer, src, dst, residual or None, relu_in, relu_out, bn or None).
+        Buffer 'x' is the network input; the last dst is the hidden state the final layer reads."""
+        steps = [(self.initial_layer, 'x', 'h0', None, False, False, None)]
+        cur = 'h0'
+        for i, block in enumerate(self.blocks):
+            if isinstance(block, MaskedResidualBlock):
+                bn = block.batch_norm_layers if block.use_batch_norm else (None, None)
+                steps.append((block.linear_layers[0], cur, 't%d' % i, None, True, False, bn[0]))
+                steps.append((block.linear_layers[1], 't%d' % i, 'h%d' % (i + 1), cur, True, False, bn[1]))
+            else:
+                steps.append((block.linear, cur, 'h%d' % (i + 1), None, False, True, block.batch_norm))
+            cur = 'h%d' % (i + 1)
+        return steps, cur
+
+    def hidden_degrees(self):
+        """Sorted MADE degrees that occur on any hidden unit."""
+        degs = set()
+        for layer, *_ in self.hidden_program()[0]:
+            degs.update(layer.degrees.cpu().tolist())
+        return sorted(degs)
+
+    def run_hidden_program(self, bufs, degree=None):
+        """Runs the hidden stack into `bufs` (dict name -> [B, hidden] tensor, 'x' = input).  With `degree`
+        only the output tiles that hold units of that degree are recomputed - everything a change of
+        input feature `degree - 1` can alter that later features need (see transforms.py)."""
+        steps, last = self.hidden_program()
+        for layer, src, dst, res, relu_in, relu_out, bn in steps:
+            tiles = None
+            if degree is not None:
+                tiles = layer.tiles_of_degree(degree)
+                if tiles is None:
+                    continue
+            sc, sh = _bn_scale_shift(bn) if bn is not None else (None, None)
+            layer.fused(bufs[src], residual=None if res is None else bufs[res], in_scale=sc, in_shift=sh,
+                        relu_in=relu_in, relu_out=relu_out, out=bufs[dst], tiles=tiles)
+        return bufs[last]
 
     def forward(self, inputs, context=None):
         return self.final_layer.fused(self.forward_hidden(inputs, context))

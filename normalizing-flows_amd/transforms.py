@@ -184,6 +184,61 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                              min_derivative=self.min_derivative, want_bins=want_bins)
 
+    def _feature_groups(self):
+        """Consecutive features that can be inverted in the same pass.  Feature i (0-based, MADE degree
+        i+1) sees hidden units of degree <= i, and input i-1 reaches it only through units of degree
+        exactly i; where no hidden unit has that degree, feature i does not depend on feature i-1 and
+        joins its pass.  D=784, H=512: 513 single-feature passes, then features 513..783 together."""
+        net = self.autoregressive_net
+        key = tuple(net.hidden_degrees())
+        c = getattr(self, '_groups_cache', None)
+        if c is None or c[0] != key:
+            D = net.initial_layer.in_features
+            present = set(key)
+            groups, a = [], 0
+            for i in range(1, D):
+                if i in present:
+                    groups.append((a, i - 1))
+                    a = i
+            groups.append((a, D - 1))
+            object.__setattr__(self, '_groups_cache', (key, groups))
+        return self._groups_cache[1]
+
+    def inverse(self, inputs, context=None):
+        """Same result as the reference's D full passes (transforms.py:493-500), computed incrementally:
+        after the pass that fixes feature i-1 only the hidden units of degree i can change among those
+        later features still read, so a pass recomputes just their 128-column tiles in every hidden
+        layer and the one fused final-layer tile that holds the features being fixed.  Features not yet
+        fixed stay exactly zero in the network input, as in the reference's first pass."""
+        net = self.autoregressive_net
+        if context is not None or not self._fusable():
+            return super().inverse(inputs, context)
+        D = net.initial_layer.in_features
+        _check_2d(inputs, D)
+        made_module._require_inference(net.final_layer)
+        B = inputs.shape[0]
+        H = net.final_layer.in_features
+        pf = net.final_layer._packed_fused_final(D, self.num_bins, self.tails)
+        fpt = 256 // self._output_dim_multiplier()        # whole features per fused column tile
+        outputs = torch.zeros_like(inputs)
+        logabsdet = torch.zeros(B, dtype=inputs.dtype, device=inputs.device)
+        groups = self._feature_groups()
+        names = {n for st in net.hidden_program()[0] for n in (st[1], st[2])} - {'x'}
+        for s in range(0, B, CHUNK_ROWS):
+            e = min(B, s + CHUNK_ROWS)
+            z, out = inputs[s:e], outputs[s:e]
+            bufs = {n: torch.empty((e - s, H), dtype=inputs.dtype, device=inputs.device) for n in names}
+            bufs['x'] = out
+            ws = torch.empty(pf.tiles * (e - s), dtype=torch.float32, device=inputs.device)
+            for gi, (a, b) in enumerate(groups):
+                hidden = net.run_hidden_program(bufs, degree=None if gi == 0 else a)
+                t0, t1 = a // fpt, b // fpt
+                _lib.made_rqs(hidden, pf, z, self.tail_bound, inverse=True, out=out, logabsdet=logabsdet[s:e],
+                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                              min_derivative=self.min_derivative, tiles=(t0, t1 - t0 + 1), feat_limit=b + 1,
+                              reduce=gi == len(groups) - 1, workspace=ws)
+        return outputs, logabsdet
+
     def forward_with_bins(self, inputs, context=None):
         """forward() that also returns the int32 bin index of every element (-1 in the tails): the
         searchsorted result (helper_functions.py:507-512) that parity tests compare bit for bit."""
