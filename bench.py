@@ -32,6 +32,10 @@ D, H, K, T, L = 784, 512, 8, 3.0, 5
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
+# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE doubled as the
+# microarch guide prescribes for gfx950, + WRITE_SIZE), collected separately: profiles/r01_f_f32_fused_pmc.txt.
+# Keyed by (dtype, fused kernel?, rows per launch); other shapes report null.
+TRAFFIC_BYTES_PER_LAUNCH = {('f32', True, 131072): 7.07e9}
 
 
 def build_flow(nf):
@@ -153,7 +157,7 @@ def main():
                                'kernel': ('made_rqs_kernel<%s> (final layer 512->18032 fused with the spline)' if fused
                                           else 'masked_linear_%s_kernel (final layer 512->18032)') % args.dtype,
                                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                               'traffic': None, 'launches': n, 'avg_launch_ms': ms, 'rows_per_launch': rows,
+                               'traffic': TRAFFIC_BYTES_PER_LAUNCH.get((args.dtype, fused, rows)), 'launches': n, 'avg_launch_ms': ms, 'rows_per_launch': rows,
                                'algorithmic_flop_per_launch': flop,
                                'dense_equiv_tflops': 2.0 * final.out_features * final.in_features * rows / (ms * 1e-3) / 1e12}
         rq = [k for k in kern if k[0] == 'rqs']

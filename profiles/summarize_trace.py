@@ -9,9 +9,8 @@ def main(path, min_share=0.05):
     groups = defaultdict(list)
     with open(path) as f:
         for r in csv.DictReader(f):
-            name = r['Kernel_Name']
-            short = name.split('(')[0] if not name.startswith('(') else name.split('::', 1)[1].split('(')[0]
-            short = short.replace('void ', '').replace('(anonymous namespace)::', '')
+            name = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '')
+            short = name.split('(')[0]
             key = (short[:70], int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])),
                    int(r['VGPR_Count']), int(r['Accum_VGPR_Count']), int(r['LDS_Block_Size']))
             groups[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
