@@ -146,6 +146,36 @@ int nf_affine_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_inde
                   float* y, int64_t y_row_stride, float* logabsdet, int accumulate,
                   int64_t B, int D, int inverse, void* stream);
 
+/* ---- backward kernels (maximum-likelihood training; the reference differentiates the same op sequences
+ *      with autograd: test2.py:127-135, model.py:233-244) ---------------------------------------------- */
+
+/* Transposed pack of (W*mask): the weight operand of grad_x = grad_y @ (W*mask).  Buffer sizes:
+ * nf_made_packed_bytes(in, out, dtype) and nf_made_ktab_len(in). */
+int nf_made_pack_t(const float* W, const float* mask, int out, int in, int dtype, void* packed_t,
+                   int32_t* ktab_t, void* stream);
+/* grad_x[B,in] = grad_y[B,out] @ (W*mask), zeroed where gate <= 0; gate = the layer's forward input when it
+ * applied ReLU to it (relu_in), else NULL. */
+int nf_masked_linear_bwd_input(const float* grad_y, int64_t grad_y_row_stride, const void* packed_wt,
+                               const int32_t* ktab_t, const float* gate, int64_t gate_row_stride,
+                               float* grad_x, int64_t grad_x_row_stride, int64_t B, int in, int out,
+                               int dtype, void* stream);
+/* grad_w[out,in] += mask * (grad_y^T @ act(x)); grad_b[out] += column sums of grad_y (either may be NULL).
+ * ACCUMULATING: zero the buffers before the first call.  fp32 atomics are used when the batch is split
+ * over workgroups (last bits depend on arrival order).  ktab (nullable) = the layer's forward K-tile table.
+ * Requires in % 4 == 0, out % 4 == 0 and 16-byte aligned rows. */
+int nf_masked_linear_bwd_weight(const float* x, int64_t x_row_stride, const float* grad_y,
+                                int64_t grad_y_row_stride, const float* mask, const int32_t* ktab,
+                                float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
+                                int dtype, void* stream);
+/* Backward of nf_rqs_fwd(inverse=0, feat_index=NULL): from x, params (recomputed, nothing saved from the
+ * forward), grad_y[B,D] and grad_logabsdet[B] to grad_x[B,D] (the spline's direct part) and
+ * grad_params[B, D*P] (contiguous rows). */
+int nf_rqs_bwd(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+               double pre_div, const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
+               float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D, int K,
+               int tails, double tail_bound, double min_bin_width, double min_bin_height,
+               double min_derivative, void* stream);
+
 /* ---- legacy Gaussian MAF layer, float64 (replaces models/flows.py:239-263 MaskedAutoregressiveFlow on
  *      models/made.py:11-89 SimpleMADE; the reference runs this class in float64 only) ---------------- */
 

@@ -59,6 +59,17 @@ _SIGNATURES = {
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                    _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_int,
                                    _c.c_void_p]),
+    'nf_made_pack_t': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+                                  _c.c_void_p, _c.c_void_p]),
+    'nf_masked_linear_bwd_input': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                              _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
+                                              _c.c_int, _c.c_void_p]),
+    'nf_masked_linear_bwd_weight': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                                               _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
+                                               _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_rqs_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p, _c.c_int64,
+                              _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
+                              _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_void_p]),
     'nf_fold_f64': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     'nf_linear_f64_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
@@ -143,6 +154,76 @@ class PackedLinear:
         with torch.cuda.device(w.device):
             _check(lib.nf_made_pack(w.data_ptr(), _ptr(m), self.out, self.inp, dtype, self.packed.data_ptr(),
                                     self.ktab.data_ptr(), _stream()), 'nf_made_pack')
+
+
+class PackedLinearT:
+    """Transposed pack (nf_made_pack_t) for the input-gradient GEMM of one [out,in] layer."""
+    __slots__ = ('out', 'inp', 'dtype', 'packed', 'ktab')
+
+    def __init__(self, weight, mask, dtype=NF_DTYPE_F32):
+        lib = load()
+        w = _dev(weight.detach().contiguous(), 'weight')
+        m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
+        self.out, self.inp, self.dtype = int(w.shape[0]), int(w.shape[1]), dtype
+        self.packed = torch.empty(lib.nf_made_packed_bytes(self.inp, self.out, dtype), dtype=torch.uint8,
+                                  device=w.device)
+        self.ktab = torch.empty(lib.nf_made_ktab_len(self.inp), dtype=torch.int32, device=w.device)
+        with torch.cuda.device(w.device):
+            _check(lib.nf_made_pack_t(w.data_ptr(), _ptr(m), self.out, self.inp, dtype, self.packed.data_ptr(),
+                                      self.ktab.data_ptr(), _stream()), 'nf_made_pack_t')
+
+
+def masked_linear_bwd_input(grad_y, plt, gate=None):
+    lib = load()
+    _dev(grad_y, 'grad_y')
+    gp, gs = _rows(grad_y, 'grad_y')
+    B = grad_y.shape[0]
+    gx = torch.empty((B, plt.inp), dtype=torch.float32, device=grad_y.device)
+    xp, xs = _rows(gx, 'grad_x')
+    tp, ts = (None, 0) if gate is None else _rows(_dev(gate, 'gate'), 'gate')
+    with torch.cuda.device(grad_y.device):
+        _check(lib.nf_masked_linear_bwd_input(gp, gs, plt.packed.data_ptr(), plt.ktab.data_ptr(), tp, ts, xp, xs, B,
+                                              plt.inp, plt.out, plt.dtype, _stream()), 'nf_masked_linear_bwd_input')
+    return gx
+
+
+def masked_linear_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True):
+    """Returns (grad_w [out,in], grad_b [out] or None), freshly zeroed then accumulated by the kernel."""
+    lib = load()
+    _dev(x, 'x')
+    _dev(grad_y, 'grad_y')
+    xp, xs = _rows(x, 'x')
+    gp, gs = _rows(grad_y, 'grad_y')
+    B, inp = x.shape
+    out = grad_y.shape[1]
+    gw = torch.zeros((out, inp), dtype=torch.float32, device=x.device)
+    gb = torch.zeros(out, dtype=torch.float32, device=x.device) if want_bias else None
+    m = None if mask is None else _dev(mask.contiguous(), 'mask')
+    with torch.cuda.device(x.device):
+        _check(lib.nf_masked_linear_bwd_weight(xp, xs, gp, gs, _ptr(m), _ptr(ktab), gw.data_ptr(), _ptr(gb), B, inp, out,
+                                               int(relu_in), NF_DTYPE_F32, _stream()), 'nf_masked_linear_bwd_weight')
+    return gw, gb
+
+
+def rqs_bwd(x, params, grad_y, grad_lad, num_bins, tails, tail_bound, pre_div=1.0, min_bin_width=1e-3,
+            min_bin_height=1e-3, min_derivative=1e-3):
+    lib = load()
+    for t, n in ((x, 'inputs'), (params, 'params'), (grad_y, 'grad_y'), (grad_lad, 'grad_logabsdet')):
+        _dev(t, n)
+    B, D = x.shape
+    xp, xs = _rows(x, 'inputs')
+    pp, ps = _rows(params, 'params')
+    gyp, gys = _rows(grad_y, 'grad_y')
+    gx = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    gxp, gxs = _rows(gx, 'grad_x')
+    gparams = torch.empty_like(params)
+    gl = grad_lad.contiguous()
+    with torch.cuda.device(x.device):
+        _check(lib.nf_rqs_bwd(xp, xs, pp, ps, float(pre_div), gyp, gys, gl.data_ptr(), gxp, gxs, gparams.data_ptr(), B,
+                              D, int(num_bins), 1 if tails == 'linear' else 0, float(tail_bound),
+                              float(min_bin_width), float(min_bin_height), float(min_derivative), _stream()),
+               'nf_rqs_bwd')
+    return gx, gparams
 
 
 class PackedFusedFinal:

@@ -1,0 +1,64 @@
+"""torch.autograd glue for training by maximum likelihood (BASELINE.json config 5).
+
+The reference trains by letting autograd differentiate its ATen op sequences (test2.py:127-135,
+model.py:233-244).  Here every forward kernel has a hand-written backward kernel and these
+``autograd.Function``s only connect them: nothing falls back to PyTorch math.
+
+  MaskedLinearFn : y = act_in(x) @ (W*mask)^T + b (+ residual)
+                   backward: grad_x = (grad_y @ (W*mask)) gated by x > 0   (nf_masked_linear_bwd_input)
+                             grad_W = mask * grad_y^T @ act_in(x), grad_b  (nf_masked_linear_bwd_weight)
+  RqsFn          : (y, logabsdet) = spline(x; params), forward direction
+                   backward: recompute-from-inputs kernel nf_rqs_bwd -> grad_x, grad_params
+"""
+import torch
+
+from . import _lib
+
+
+class MaskedLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, layer, relu_in):
+        pl = layer._packed_linear()
+        y = _lib.masked_linear(x, pl, residual=residual, relu_in=relu_in)
+        ctx.save_for_backward(x)
+        ctx.layer = layer
+        ctx.relu_in = relu_in
+        ctx.has_residual = residual is not None
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        (x,) = ctx.saved_tensors
+        layer = ctx.layer
+        grad_y = grad_y.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if ctx.relu_in else None)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = _lib.masked_linear_bwd_weight(x, grad_y, getattr(layer, 'mask', None), layer._packed_linear().ktab,
+                                                   ctx.relu_in, want_bias=ctx.has_bias)
+        gres = grad_y if ctx.has_residual else None
+        return gx, gw, gb, gres, None, None
+
+
+class RqsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, params, num_bins, tails, tail_bound, mins):
+        y, lad, _ = _lib.rqs(x, params, num_bins, tails, tail_bound, min_bin_width=mins[0], min_bin_height=mins[1],
+                             min_derivative=mins[2])
+        ctx.save_for_backward(x, params)
+        ctx.cfg = (num_bins, tails, tail_bound, mins)
+        return y, lad
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_lad):
+        x, params = ctx.saved_tensors
+        num_bins, tails, tail_bound, mins = ctx.cfg
+        if grad_y is None:
+            grad_y = torch.zeros_like(x)
+        if grad_lad is None:
+            grad_lad = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
+        gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
+                                   min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2])
+        return gx, gparams, None, None, None, None

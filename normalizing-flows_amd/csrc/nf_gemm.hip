@@ -38,6 +38,8 @@ struct GemmArgs {
     const float* in_shift;
     float* y;
     int64_t ldy;
+    const float* gate;       // nullable [M, N]: outputs are zeroed where gate <= 0 (ReLU backward)
+    int64_t ldg;
     int64_t M;
     int N, K;
     int relu_in, relu_out;
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(GT, 2) void masked_linear_f32_kernel(const GemmArgs
                 float v = acc[i][j][r] + bv;
                 if (g.res) v += g.res[row * g.ldr + col];
                 if (g.relu_out) v = fmaxf(v, 0.0f);
+                if (g.gate) v = g.gate[row * g.ldg + col] > 0.0f ? v : 0.0f;
                 g.y[row * g.ldy + col] = v;
             }
         }
@@ -370,42 +373,192 @@ __global__ __launch_bounds__(GT, 2) void masked_linear_bf16_kernel(const GemmArg
                 float v = acc[i][j][r] + bv;
                 if (g.res) v += g.res[row * g.ldr + col];
                 if (g.relu_out) v = fmaxf(v, 0.0f);
+                if (g.gate) v = g.gate[row * g.ldg + col] > 0.0f ? v : 0.0f;
                 g.y[row * g.ldy + col] = v;
             }
         }
 }
 
+// ---- weight gradient ---------------------------------------------------------------------------------
+// grad_W[n,k] += mask[n,k] * sum_b grad_y[b,n] * act(x[b,k])   (autograd of made.py:152 `W*mask`: the mask
+// re-applied to the gradient).  A "TN" GEMM: both operands are row-major with the reduction index b as the
+// slow one, so tiles of 32 batch rows are staged [b][n] / [b][k] (rows padded to 132 floats) and an MFMA lane
+// reads A[n = lane&31][b = lane>>5] with one conflict-free ds_read_b32.  128 x 128 outputs per block, 4 waves
+// as 2x2; the batch is split over gridDim.z and partial tiles are added with fp32 atomics when split.
+// Output tiles with no unmasked weight (the forward K-tile table) exit immediately.
+constexpr int WB = 32;                 // batch rows per staged tile
+constexpr int WLD = 132;               // padded LDS row (floats)
+
+struct WgradArgs {
+    const float* x;
+    int64_t ldx;
+    const float* gy;
+    int64_t ldgy;
+    const float* mask;       // nullable [out, in]
+    const int32_t* ktab;     // nullable: forward K-tile table, [out/128][2] in 32-wide units
+    float* gw;               // [out, in], accumulated into
+    int64_t M;               // batch rows
+    int out, in;
+    int relu_in;
+    int splits;
+};
+
+__device__ __forceinline__ float4 ld4_rows(const float* base, int64_t ld, int64_t row, int64_t M, int col, int ncols) {
+    // rows past M and columns past ncols contribute zeros (clamped address, select afterwards)
+    const int64_t r = min(row, M - 1);
+    const int c = min(col, ncols - 4);
+    float4 v = *reinterpret_cast<const float4*>(base + r * ld + c);
+    const bool ok = row < M && col < ncols;
+    v.x = ok ? v.x : 0.f;
+    v.y = ok ? v.y : 0.f;
+    v.z = ok ? v.z : 0.f;
+    v.w = ok ? v.w : 0.f;
+    return v;
+}
+
+__global__ __launch_bounds__(GT, 2) void wgrad_f32_kernel(const WgradArgs g) {
+    __shared__ __attribute__((aligned(16))) float Ys[WB * WLD];
+    __shared__ __attribute__((aligned(16))) float Xs[WB * WLD];
+    const int tn = blockIdx.x, tk = blockIdx.y;
+    const int n0 = tn * 128, k0 = tk * 128;
+    if (g.ktab) {
+        const int kb = g.ktab[2 * tn] * 32, ke = g.ktab[2 * tn + 1] * 32;
+        if (k0 >= ke || k0 + 128 <= kb) return;            // fully masked tile
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t per = ((g.M + g.splits - 1) / g.splits + WB - 1) / WB * WB;
+    const int64_t b_begin = (int64_t)blockIdx.z * per, b_end = min(g.M, b_begin + per);
+    if (b_begin >= b_end) return;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // staging: float4 v = tid + 256*i -> row v>>5 (= srow + 8*i), col 4*(v&31)
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    float4 y0, y1, y2, y3, x0, x1, x2, x3;
+#define NF_WG_LOAD(B0)                                                              \
+    do {                                                                            \
+        const int64_t b_ = (B0) + srow;                                             \
+        y0 = ld4_rows(g.gy, g.ldgy, b_, b_end, n0 + scol, g.out);                   \
+        y1 = ld4_rows(g.gy, g.ldgy, b_ + 8, b_end, n0 + scol, g.out);               \
+        y2 = ld4_rows(g.gy, g.ldgy, b_ + 16, b_end, n0 + scol, g.out);              \
+        y3 = ld4_rows(g.gy, g.ldgy, b_ + 24, b_end, n0 + scol, g.out);              \
+        x0 = ld4_rows(g.x, g.ldx, b_, b_end, k0 + scol, g.in);                      \
+        x1 = ld4_rows(g.x, g.ldx, b_ + 8, b_end, k0 + scol, g.in);                  \
+        x2 = ld4_rows(g.x, g.ldx, b_ + 16, b_end, k0 + scol, g.in);                 \
+        x3 = ld4_rows(g.x, g.ldx, b_ + 24, b_end, k0 + scol, g.in);                 \
+    } while (0)
+    auto relu4 = [&](float4 v) {
+        if (g.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        return v;
+    };
+
+    NF_WG_LOAD(b_begin);
+    for (int64_t b0 = b_begin; b0 < b_end; b0 += WB) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(&Ys[srow * WLD + scol]) = y0;
+        *reinterpret_cast<float4*>(&Ys[(srow + 8) * WLD + scol]) = y1;
+        *reinterpret_cast<float4*>(&Ys[(srow + 16) * WLD + scol]) = y2;
+        *reinterpret_cast<float4*>(&Ys[(srow + 24) * WLD + scol]) = y3;
+        *reinterpret_cast<float4*>(&Xs[srow * WLD + scol]) = relu4(x0);
+        *reinterpret_cast<float4*>(&Xs[(srow + 8) * WLD + scol]) = relu4(x1);
+        *reinterpret_cast<float4*>(&Xs[(srow + 16) * WLD + scol]) = relu4(x2);
+        *reinterpret_cast<float4*>(&Xs[(srow + 24) * WLD + scol]) = relu4(x3);
+        __syncthreads();
+        NF_WG_LOAD(min(b0 + WB, b_end - 1));        // prefetch (the last one re-reads, its rows are masked to zero)
+        __builtin_amdgcn_sched_barrier(0);
+        const int fr = lane & 31, fb = lane >> 5;
+#pragma unroll
+        for (int bb = 0; bb < WB; bb += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = Ys[(bb + fb) * WLD + wr * 64 + i * 32 + fr];
+                b[i] = Xs[(bb + fb) * WLD + wc * 64 + i * 32 + fr];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#undef NF_WG_LOAD
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wc * 64 + j * 32 + (lane & 31);
+            if (k >= g.in) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n >= g.out) continue;
+                const int64_t idx = (int64_t)n * g.in + k;
+                float v = acc[i][j][r];
+                if (g.mask) v *= g.mask[idx];
+                if (g.splits > 1) atomicAdd(&g.gw[idx], v);
+                else g.gw[idx] += v;
+            }
+        }
+}
+
+// grad_b[n] += sum_b grad_y[b,n]: 64 columns x 4 row lanes per block, rows split over gridDim.y, fp32 atomics.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ gy, int64_t ldgy, int64_t M, int out,
+                                                     float* __restrict__ gb) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int64_t per = (M + gridDim.y - 1) / gridDim.y;
+    const int64_t b0 = (int64_t)blockIdx.y * per, b1 = min(M, b0 + per);
+    float s = 0.f;
+    if (n < out)
+        for (int64_t b = b0 + rl; b < b1; b += 4) s += gy[b * ldgy + n];
+    part[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && n < out) atomicAdd(&gb[n], part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+
 // ---- packing ---------------------------------------------------------------------------------
+// Logical matrix element (n, k) lives at W[n*sn + k*sk]: (sn, sk) = (in, 1) packs W itself, (1, out_src)
+// packs its transpose (the operand of the input-gradient GEMM).
 __global__ void pack_f32_kernel(const float* __restrict__ W, const float* __restrict__ mask, int out, int in,
-                                int kpad, int64_t total, float* __restrict__ packed) {
+                                int64_t sn, int64_t sk, int kpad, int64_t total, float* __restrict__ packed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = i / kpad;
         const int k = (int)(i - n * kpad);
         float v = 0.0f;
         if (n < out && k < in) {
-            v = W[n * in + k];
-            if (mask) v *= mask[n * in + k];
+            v = W[n * sn + k * sk];
+            if (mask) v *= mask[n * sn + k * sk];
         }
         packed[i] = v;
     }
 }
 
 __global__ void pack_bf16_kernel(const float* __restrict__ W, const float* __restrict__ mask, int out, int in,
-                                 int kpad, int64_t total, __bf16* __restrict__ packed) {
+                                 int64_t sn, int64_t sk, int kpad, int64_t total, __bf16* __restrict__ packed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = i / kpad;
         const int k = (int)(i - n * kpad);
         float v = 0.0f;
         if (n < out && k < in) {
-            v = W[n * in + k];
-            if (mask) v *= mask[n * in + k];
+            v = W[n * sn + k * sk];
+            if (mask) v *= mask[n * sn + k * sk];
         }
         packed[i] = (__bf16)v;
     }
 }
 
-__global__ __launch_bounds__(256) void ktab_kernel(const float* __restrict__ mask, int out, int in, int kpad,
-                                                   int32_t* __restrict__ ktab) {
+__global__ __launch_bounds__(256) void ktab_kernel(const float* __restrict__ mask, int out, int in, int64_t sn,
+                                                   int64_t sk, int32_t* __restrict__ ktab) {
     __shared__ int lo, hi;
     const int tn = blockIdx.x;
     if (threadIdx.x == 0) { lo = 0x7fffffff; hi = -1; }
@@ -415,7 +568,7 @@ __global__ __launch_bounds__(256) void ktab_kernel(const float* __restrict__ mas
         const int rows = min(BN, out - tn * BN);
         for (int64_t i = threadIdx.x; i < (int64_t)rows * in; i += blockDim.x) {
             const int r = (int)(i / in), k = (int)(i - (int64_t)r * in);
-            if (mask[(int64_t)(tn * BN + r) * in + k] != 0.0f) { mylo = min(mylo, k); myhi = max(myhi, k); }
+            if (mask[(int64_t)(tn * BN + r) * sn + k * sk] != 0.0f) { mylo = min(mylo, k); myhi = max(myhi, k); }
         }
     } else {
         mylo = 0;
@@ -443,8 +596,8 @@ extern "C" size_t nf_made_packed_bytes(int out, int in, int dtype) {
 
 extern "C" int nf_made_ktab_len(int out) { return out <= 0 ? 0 : 2 * n_tiles_of(out); }
 
-extern "C" int nf_made_pack(const float* W, const float* mask, int out, int in, int dtype, void* packed,
-                            int32_t* ktab, void* stream) {
+static int pack_impl(const float* W, const float* mask, int out, int in, int64_t sn, int64_t sk, int dtype,
+                     void* packed, int32_t* ktab, void* stream) {
     if (!W || !packed || !ktab) return NF_ERR_NULL;
     if (out <= 0 || in <= 0) return NF_ERR_SHAPE;
     if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
@@ -453,18 +606,32 @@ extern "C" int nf_made_pack(const float* W, const float* mask, int out, int in, 
     const int64_t total = (int64_t)n_tiles_of(out) * BN * kpad;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == NF_DTYPE_F32)
-        hipLaunchKernelGGL(pack_f32_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, kpad, total, (float*)packed);
+        hipLaunchKernelGGL(pack_f32_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, sn, sk, kpad, total,
+                           (float*)packed);
     else
-        hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, kpad, total, (__bf16*)packed);
-    hipLaunchKernelGGL(ktab_kernel, dim3(n_tiles_of(out)), dim3(256), 0, s, mask, out, in, kpad, ktab);
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, sn, sk, kpad, total,
+                           (__bf16*)packed);
+    hipLaunchKernelGGL(ktab_kernel, dim3(n_tiles_of(out)), dim3(256), 0, s, mask, out, in, sn, sk, ktab);
     return nf_launch_status();
 }
 
-extern "C" int nf_masked_linear_fwd_tiles(const float* x, int64_t x_row_stride, const void* packed_w,
-                                          const int32_t* ktab, const float* bias, const float* residual,
-                                          int64_t residual_row_stride, const float* in_scale, const float* in_shift,
-                                          float* y, int64_t y_row_stride, int64_t B, int in, int out, int relu_in,
-                                          int relu_out, int dtype, int n_tile_begin, int n_tile_count, void* stream) {
+extern "C" int nf_made_pack(const float* W, const float* mask, int out, int in, int dtype, void* packed,
+                            int32_t* ktab, void* stream) {
+    return pack_impl(W, mask, out, in, in, 1, dtype, packed, ktab, stream);
+}
+
+// Packs the TRANSPOSE of (W*mask): a logical [in, out] matrix, the weight operand of grad_x = grad_y @ (W*mask).
+// Buffer sizes: nf_made_packed_bytes(in, out, dtype) and nf_made_ktab_len(in).
+extern "C" int nf_made_pack_t(const float* W, const float* mask, int out, int in, int dtype, void* packed_t,
+                              int32_t* ktab_t, void* stream) {
+    return pack_impl(W, mask, in, out, 1, in, dtype, packed_t, ktab_t, stream);
+}
+
+static int linear_impl(const float* x, int64_t x_row_stride, const void* packed_w, const int32_t* ktab,
+                       const float* bias, const float* residual, int64_t residual_row_stride, const float* in_scale,
+                       const float* in_shift, const float* gate, int64_t gate_row_stride, float* y,
+                       int64_t y_row_stride, int64_t B, int in, int out, int relu_in, int relu_out, int dtype,
+                       int n_tile_begin, int n_tile_count, void* stream) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (B == 0) return NF_OK;
     if (!x || !packed_w || !ktab || !y) return NF_ERR_NULL;
@@ -475,6 +642,7 @@ extern "C" int nf_masked_linear_fwd_tiles(const float* x, int64_t x_row_stride, 
     g.x = x; g.ldx = x_row_stride; g.w = (const float*)packed_w; g.kpad = kpad_of(in); g.ktab = ktab;
     g.bias = bias; g.res = residual; g.ldr = residual_row_stride; g.in_scale = in_scale; g.in_shift = in_shift;
     g.y = y; g.ldy = y_row_stride; g.M = B; g.N = out; g.K = in; g.relu_in = relu_in; g.relu_out = relu_out;
+    g.gate = gate; g.ldg = gate_row_stride;
     if (n_tile_begin < 0 || n_tile_count < 0 || n_tile_begin + n_tile_count > n_tiles_of(out)) return NF_ERR_SHAPE;
     if (n_tile_count == 0) return NF_OK;
     g.n_tiles = n_tile_count;
@@ -513,6 +681,27 @@ extern "C" int nf_masked_linear_fwd_tiles(const float* x, int64_t x_row_stride, 
     return nf_launch_status();
 }
 
+extern "C" int nf_masked_linear_fwd_tiles(const float* x, int64_t x_row_stride, const void* packed_w,
+                                          const int32_t* ktab, const float* bias, const float* residual,
+                                          int64_t residual_row_stride, const float* in_scale, const float* in_shift,
+                                          float* y, int64_t y_row_stride, int64_t B, int in, int out, int relu_in,
+                                          int relu_out, int dtype, int n_tile_begin, int n_tile_count, void* stream) {
+    return linear_impl(x, x_row_stride, packed_w, ktab, bias, residual, residual_row_stride, in_scale, in_shift, nullptr,
+                       0, y, y_row_stride, B, in, out, relu_in, relu_out, dtype, n_tile_begin, n_tile_count, stream);
+}
+
+// grad_x[B,in] = (grad_y[B,out] @ (W*mask)) zeroed where gate <= 0 (gate = the forward input when the layer
+// applied ReLU to it, else NULL): the forward kernel on the transposed pack (nf_made_pack_t).
+extern "C" int nf_masked_linear_bwd_input(const float* grad_y, int64_t grad_y_row_stride, const void* packed_wt,
+                                          const int32_t* ktab_t, const float* gate, int64_t gate_row_stride,
+                                          float* grad_x, int64_t grad_x_row_stride, int64_t B, int in, int out,
+                                          int dtype, void* stream) {
+    if (gate && gate_row_stride < in) return NF_ERR_LAYOUT;
+    return linear_impl(grad_y, grad_y_row_stride, packed_wt, ktab_t, nullptr, nullptr, 0, nullptr, nullptr, gate,
+                       gate_row_stride, grad_x, grad_x_row_stride, B, out, in, 0, 0, dtype, 0,
+                       in > 0 ? n_tiles_of(in) : 0, stream);
+}
+
 extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const void* packed_w, const int32_t* ktab,
                                     const float* bias, const float* residual, int64_t residual_row_stride,
                                     const float* in_scale, const float* in_shift, float* y, int64_t y_row_stride,
@@ -520,4 +709,42 @@ extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const 
     return nf_masked_linear_fwd_tiles(x, x_row_stride, packed_w, ktab, bias, residual, residual_row_stride, in_scale,
                                       in_shift, y, y_row_stride, B, in, out, relu_in, relu_out, dtype, 0,
                                       out > 0 ? n_tiles_of(out) : 0, stream);
+}
+
+// grad_w[out,in] += mask * (grad_y^T @ act(x)), grad_b[out] += column sums of grad_y (either may be NULL).
+// Both are ACCUMULATED (zero them before the first call); with the batch split across blocks the sums
+// use fp32 atomics, so the last bits depend on arrival order.  `ktab` (nullable) is the forward K-tile table
+// of this layer: output tiles without unmasked weights are skipped.  Requires in % 4 == 0 and out % 4 == 0.
+extern "C" int nf_masked_linear_bwd_weight(const float* x, int64_t x_row_stride, const float* grad_y,
+                                           int64_t grad_y_row_stride, const float* mask, const int32_t* ktab,
+                                           float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
+                                           int dtype, void* stream) {
+    if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
+    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
+    if (B == 0) return NF_OK;
+    if (!x || !grad_y || (!grad_w && !grad_b)) return NF_ERR_NULL;
+    if (x_row_stride < in || grad_y_row_stride < out) return NF_ERR_LAYOUT;
+    if (in % 4 || out % 4 || x_row_stride % 4 || grad_y_row_stride % 4 || (((uintptr_t)x | (uintptr_t)grad_y) & 15))
+        return NF_ERR_LAYOUT;
+    hipStream_t s = (hipStream_t)stream;
+    if (grad_w) {
+        WgradArgs g;
+        g.x = x; g.ldx = x_row_stride; g.gy = grad_y; g.ldgy = grad_y_row_stride; g.mask = mask; g.ktab = ktab;
+        g.gw = grad_w; g.M = B; g.out = out; g.in = in; g.relu_in = relu_in;
+        const int nt = n_tiles_of(out), kt = (in + 127) / 128;
+        int64_t splits = 1536 / ((int64_t)nt * kt);
+        if (splits < 1) splits = 1;
+        const int64_t max_splits = (B + 4 * WB - 1) / (4 * WB);
+        if (splits > max_splits) splits = max_splits;
+        if (splits > 65535) splits = 65535;
+        g.splits = (int)splits;
+        hipLaunchKernelGGL(wgrad_f32_kernel, dim3(nt, kt, (int)splits), dim3(GT), 0, s, g);
+    }
+    if (grad_b) {
+        int64_t rs = (B + 1023) / 1024;
+        if (rs > 256) rs = 256;
+        hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64, (int)rs), dim3(256), 0, s, grad_y, grad_y_row_stride, B,
+                           out, grad_b);
+    }
+    return nf_launch_status();
 }

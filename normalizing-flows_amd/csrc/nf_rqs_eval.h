@@ -160,3 +160,127 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
     ld = INV ? -l : l;
 }
 
+
+// ---- backward (forward direction of the spline): d(y, ld)/d(x, params) --------------------------------
+// Recomputes the forward quantities from (x, params) instead of saving ~10 intermediates per element
+// (what autograd keeps for the reference's op sequence), then overwrites the element's P parameters in
+// `p` (LDS) with their gradients.  gy = dL/dy, gl = dL/d(logabsdet of this sample).  Returns dL/dx.
+template <int KT>
+__device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, float gy, float gl, const RqsConst& a) {
+    const int K = KT > 0 ? KT : a.K;
+    const int P = a.P;
+    if (a.tails && !(x >= a.left && x <= a.right)) {   // identity tail: y = x, ld = 0
+        for (int j = 0; j < P; ++j) p[j] = 0.0f;
+        return gy;
+    }
+    float* uw = p;
+    float* uh = p + K;
+    float* ud = p + 2 * K;
+    const bool scaled = a.pre_div != 1.0f;
+    auto raw = [&](const float* u, int k) {
+        float v = u[k];
+        return scaled ? v / a.pre_div : v;
+    };
+    float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        mw = fmaxf(mw, raw(uw, k));
+        mh = fmaxf(mh, raw(uh, k));
+    }
+    constexpr int KA = KT > 0 ? KT : 1;
+    float ew[KA], eh[KA];
+    float sw = 0.0f, sh = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float w = expf(raw(uw, k) - mw), h = expf(raw(uh, k) - mh);
+        if constexpr (KT > 0) { ew[k] = w; eh[k] = h; }
+        sw += w;
+        sh += h;
+    }
+    const float rw = 1.0f / sw, rh = 1.0f / sh;
+    double accw = 0.0, acch = 0.0;
+    float kw0 = a.left, kh0 = a.left;
+    float x0 = a.left, x1 = a.left, y0 = a.left, y1 = a.left;
+    int bin = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float w, h;
+        if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
+        else { w = expf(raw(uw, k) - mw); h = expf(raw(uh, k) - mh); }
+        w = a.min_w + a.scale_w * (w * rw);
+        h = a.min_h + a.scale_h * (h * rh);
+        accw += (double)w;
+        acch += (double)h;
+        float kw1 = a.span * (float)accw + a.left;
+        float kh1 = a.span * (float)acch + a.left;
+        if (k == K - 1) { kw1 = a.right; kh1 = a.right; }
+        if (x >= kw0) { bin = k; x0 = kw0; x1 = kw1; y0 = kh0; y1 = kh1; }
+        kw0 = kw1;
+        kh0 = kh1;
+    }
+    // slopes and which raw parameter (if any) feeds each
+    int i0, i1;                      // index into ud, -1 = pinned boundary constant
+    if (a.tails) { i0 = bin == 0 ? -1 : bin - 1; i1 = bin == K - 1 ? -1 : bin; }
+    else { i0 = bin; i1 = bin + 1; }
+    const float u0 = i0 < 0 ? a.tail_const : ud[i0];
+    const float u1 = i1 < 0 ? a.tail_const : ud[i1];
+    const float d0 = a.min_d + softplus_f(u0);
+    const float d1 = a.min_d + softplus_f(u1);
+
+    const float bw = x1 - x0, bh = y1 - y0;
+    const float s = bh / bw;
+    const float t = (x - x0) / bw;
+    const float q = t * (1.0f - t), omt = 1.0f - t;
+    const float c = d0 + d1 - 2.0f * s;
+    const float N = bh * (s * t * t + d0 * q);
+    const float Dn = s + c * q;
+    const float M = d1 * t * t + 2.0f * s * q + d0 * omt * omt;
+
+    const float A = gy / Dn;                                   // dL/dN
+    const float Bc = -gy * N / (Dn * Dn) - 2.0f * gl / Dn;     // dL/dDn
+    const float Cm = gl / M;                                   // dL/dM
+    const float g_t = A * bh * (2.0f * s * t + d0 * (1.0f - 2.0f * t)) + Bc * c * (1.0f - 2.0f * t) +
+                      Cm * (2.0f * d1 * t + 2.0f * s * (1.0f - 2.0f * t) - 2.0f * d0 * omt);
+    const float g_s = A * bh * t * t + Bc * (1.0f - 2.0f * q) + Cm * 2.0f * q + 2.0f * gl / s;
+    float g_bh = A * (s * t * t + d0 * q) + g_s / bw;
+    const float g_d0 = A * bh * q + Bc * q + Cm * omt * omt;
+    const float g_d1 = Bc * q + Cm * t * t;
+    const float g_bw = -g_t * t / bw - g_s * s / bw;
+    const float gx = g_t / bw;
+    const float g_x0 = -g_t / bw - g_bw, g_x1 = g_bw;
+    const float g_y0 = gy - g_bh, g_y1 = g_bh;
+
+    // knots b and b+1 move with the widths / heights only when they are interior (ends are pinned)
+    const float Gw0 = (bin >= 1) ? a.span * g_x0 : 0.0f, Gw1 = (bin + 1 <= K - 1) ? a.span * g_x1 : 0.0f;
+    const float Gh0 = (bin >= 1) ? a.span * g_y0 : 0.0f, Gh1 = (bin + 1 <= K - 1) ? a.span * g_y1 : 0.0f;
+    // d knot_k / d w_j = [j < k]:  g_w_j = Gw0 [j < bin] + Gw1 [j <= bin], through w = min + scale * softmax
+    float dotw = 0.0f, doth = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float w, h;
+        if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
+        else { w = expf(raw(uw, k) - mw); h = expf(raw(uh, k) - mh); }
+        const float gw = a.scale_w * ((k < bin ? Gw0 : 0.0f) + (k <= bin ? Gw1 : 0.0f));
+        const float gh = a.scale_h * ((k < bin ? Gh0 : 0.0f) + (k <= bin ? Gh1 : 0.0f));
+        dotw += (w * rw) * gw;
+        doth += (h * rh) * gh;
+    }
+    const float sig0 = 1.0f / (1.0f + expf(-u0)), sig1 = 1.0f / (1.0f + expf(-u1));
+    const int nd = P - 2 * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float w, h;
+        if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
+        else { w = expf(raw(uw, k) - mw); h = expf(raw(uh, k) - mh); }
+        const float gw = a.scale_w * ((k < bin ? Gw0 : 0.0f) + (k <= bin ? Gw1 : 0.0f));
+        const float gh = a.scale_h * ((k < bin ? Gh0 : 0.0f) + (k <= bin ? Gh1 : 0.0f));
+        float ow = (w * rw) * (gw - dotw), oh = (h * rh) * (gh - doth);
+        if (scaled) { ow = ow / a.pre_div; oh = oh / a.pre_div; }
+        uw[k] = ow;
+        uh[k] = oh;
+    }
+    for (int j = 0; j < nd; ++j) ud[j] = 0.0f;
+    if (i0 >= 0) ud[i0] = g_d0 * sig0;
+    if (i1 >= 0) ud[i1] = g_d1 * sig1;
+    return gx;
+}

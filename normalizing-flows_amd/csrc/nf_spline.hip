@@ -129,6 +129,90 @@ __global__ __launch_bounds__(kThreads) void rqs_kernel(const RqsArgs a) {
     }
 }
 
+// ---- backward of the forward-direction spline (training by maximum likelihood) ------------------------
+struct RqsBwdArgs {
+    const float* x;
+    int64_t x_stride;
+    const float* params;       // [B, D*P] contiguous (the forward's conditioner output)
+    int64_t n_param_floats;
+    const float* gy;           // [B, D] dL/dy
+    int64_t gy_stride;
+    const float* glad;         // [B]    dL/dlogabsdet
+    float* gx;                 // [B, D] dL/dx through the spline only (the conditioner adds its own part)
+    int64_t gx_stride;
+    float* gparams;            // [B, D*P] contiguous
+    int64_t B;
+    int D;
+    RqsConst c;
+    int rows_per_block;
+    int vec_ok;                // params AND gparams 16-byte aligned
+};
+
+template <int KT, int MAXV>
+__global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int P = a.c.P;
+    const int D = a.D;
+    const int64_t row0 = (int64_t)blockIdx.x * a.rows_per_block;
+    const int nrows = (int)min((int64_t)a.rows_per_block, a.B - row0);
+    const int E = nrows * D;
+    float* stage = smem;
+    for (int it0 = 0; it0 < E; it0 += kThreads) {
+        const int n = min(kThreads, E - it0);
+        const int64_t g0 = (row0 * D + it0) * (int64_t)P;
+        const int64_t a0 = g0 & ~(int64_t)3;
+        const int shift = (int)(g0 - a0);
+        const int nvec = (int)((shift + (int64_t)n * P + 3) >> 2);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = tid + i * kThreads;
+            if (v < nvec)
+                *reinterpret_cast<float4*>(stage + 4 * v) = load_vec(a.params, a0 + 4 * (int64_t)v, a.n_param_floats, a.vec_ok);
+        }
+        __syncthreads();
+        if (tid < n) {
+            const int e = it0 + tid;
+            const int r = e / D;
+            const int d = e - r * D;
+            const float xv = a.x[(row0 + r) * a.x_stride + d];
+            const float gyv = a.gy[(row0 + r) * a.gy_stride + d];
+            const float gl = a.glad[row0 + r];
+            a.gx[(row0 + r) * a.gx_stride + d] = rqs_bwd_eval<KT>(stage + shift + tid * P, xv, gyv, gl, a.c);
+        }
+        __syncthreads();
+        // write the gradients of this span back: whole 16-byte vectors inside the span, scalars at its ends
+        const int64_t lo = g0, hi = g0 + (int64_t)n * P;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = tid + i * kThreads;
+            if (v >= nvec) continue;
+            const int64_t f = a0 + 4 * (int64_t)v;
+            const float4 val = *reinterpret_cast<const float4*>(stage + 4 * v);
+            if (a.vec_ok && f >= lo && f + 3 < hi) {
+                *reinterpret_cast<float4*>(a.gparams + f) = val;
+            } else {
+                if (f >= lo && f < hi) a.gparams[f] = val.x;
+                if (f + 1 >= lo && f + 1 < hi) a.gparams[f + 1] = val.y;
+                if (f + 2 >= lo && f + 2 < hi) a.gparams[f + 2] = val.z;
+                if (f + 3 >= lo && f + 3 < hi) a.gparams[f + 3] = val.w;
+            }
+        }
+    }
+}
+
+template <int KT>
+int launch_rqs_bwd_k(const RqsBwdArgs& a, int grid, size_t lds, hipStream_t s) {
+    const int nv = (kThreads * a.c.P + 4 + 3) / 4;
+    const int per = (nv + kThreads - 1) / kThreads;
+    if (per <= 6) hipLaunchKernelGGL((rqs_bwd_kernel<KT, 6>), dim3(grid), dim3(kThreads), lds, s, a);
+    else if (per <= 12) hipLaunchKernelGGL((rqs_bwd_kernel<KT, 12>), dim3(grid), dim3(kThreads), lds, s, a);
+    else if (per <= 25) hipLaunchKernelGGL((rqs_bwd_kernel<KT, 25>), dim3(grid), dim3(kThreads), lds, s, a);
+    else return NF_ERR_SHAPE;
+    return nf_launch_status();
+}
+
 struct AffineArgs {
     const float* x;
     int64_t x_stride;
@@ -274,4 +358,36 @@ extern "C" int nf_affine_fwd(const float* x, int64_t x_row_stride, const int32_t
     if (inverse) hipLaunchKernelGGL(affine_kernel<true>, dim3((int)grid), dim3(kThreads), lds, s, a);
     else hipLaunchKernelGGL(affine_kernel<false>, dim3((int)grid), dim3(kThreads), lds, s, a);
     return nf_launch_status();
+}
+
+extern "C" int nf_rqs_bwd(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                          double pre_div, const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
+                          float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D, int K,
+                          int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                          double min_derivative, void* stream) {
+    if (B < 0 || D <= 0 || K <= 0 || K > 32) return NF_ERR_SHAPE;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+    if (B == 0) return NF_OK;
+    if (!x || !params || !grad_y || !grad_logabsdet || !grad_x || !grad_params) return NF_ERR_NULL;
+    const int P = tails ? 3 * K - 1 : 3 * K + 1;
+    if (param_row_stride != (int64_t)D * P) return NF_ERR_LAYOUT;
+    if (x_row_stride < D || grad_y_row_stride < D || grad_x_row_stride < D) return NF_ERR_LAYOUT;
+    RqsBwdArgs a;
+    a.x = x; a.x_stride = x_row_stride; a.params = params; a.n_param_floats = B * (int64_t)D * P;
+    a.gy = grad_y; a.gy_stride = grad_y_row_stride; a.glad = grad_logabsdet; a.gx = grad_x;
+    a.gx_stride = grad_x_row_stride; a.gparams = grad_params; a.B = B; a.D = D;
+    a.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, pre_div);
+    a.rows_per_block = pick_rows_per_block(D, B);
+    a.vec_ok = (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0;
+    const size_t lds = sizeof(float) * (size_t)((kThreads * P + 4 + 3) & ~3);
+    const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
+    if (grid > 0x7fffffff) return NF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+        case 4: return launch_rqs_bwd_k<4>(a, (int)grid, lds, s);
+        case 8: return launch_rqs_bwd_k<8>(a, (int)grid, lds, s);
+        case 10: return launch_rqs_bwd_k<10>(a, (int)grid, lds, s);
+        case 16: return launch_rqs_bwd_k<16>(a, (int)grid, lds, s);
+        default: return launch_rqs_bwd_k<0>(a, (int)grid, lds, s);
+    }
 }

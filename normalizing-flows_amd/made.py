@@ -43,11 +43,16 @@ def _get_input_degrees(in_features):
     return torch.arange(1, in_features + 1)
 
 
+def _training(module):
+    """True when autograd should record this call (grad mode on and the layer has trainable parameters)."""
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters(recurse=False))
+
+
 def _require_inference(module, activation=None):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters(recurse=False)):
+    if _training(module):
         raise NotImplementedError(
-            'normalizing-flows_amd runs the HIP inference path only: call under torch.no_grad() '
-            '(backward kernels are not part of this build).')
+            'this configuration has no backward kernel: call under torch.no_grad() (trainable today: '
+            'residual-block MADE without BatchNorm / context, RQ-spline autoregressive transform)')
 
 
 class _PackedMixin:
@@ -76,9 +81,24 @@ class _PackedMixin:
             cached = self._fused_cache
         return cached[1]
 
+    def _packed_linear_t(self):
+        """Transposed pack for the input-gradient GEMM, cached like the forward pack."""
+        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        cached = getattr(self, '_pack_t_cache', None)
+        if cached is None or cached[0] != key:
+            plt = _lib.PackedLinearT(self.weight, getattr(self, 'mask', None), _lib.NF_DTYPE_F32)
+            object.__setattr__(self, '_pack_t_cache', (key, plt))
+            cached = self._pack_t_cache
+        return cached[1]
+
     def fused(self, x, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False, out=None,
               tiles=None):
-        _require_inference(self)
+        if _training(self) or (torch.is_grad_enabled() and x.requires_grad):
+            if in_scale is not None or relu_out or out is not None or tiles is not None:
+                _require_inference(self)
+                raise NotImplementedError('no backward kernel for BatchNorm / feed-forward blocks')
+            from .autograd import MaskedLinearFn
+            return MaskedLinearFn.apply(x, self.weight, self.bias, residual, self, bool(relu_in))
         return _lib.masked_linear(x, self._packed_linear(), residual=residual, in_scale=in_scale,
                                   in_shift=in_shift, relu_in=relu_in, relu_out=relu_out, out=out, tiles=tiles)
 

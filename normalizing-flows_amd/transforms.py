@@ -68,8 +68,13 @@ class AutoregressiveTransform(nn.Module):
         super().__init__()
         self.autoregressive_net = autoregressive_net
 
+    def _recording(self, inputs):
+        return torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def forward(self, inputs, context=None):
         _check_2d(inputs, self.autoregressive_net.initial_layer.in_features)
+        if self._recording(inputs):
+            return self._forward_autograd(inputs, context)
         B = inputs.shape[0]
         outputs = torch.empty_like(inputs)
         logabsdet = torch.empty(B, dtype=inputs.dtype, device=inputs.device)
@@ -79,8 +84,13 @@ class AutoregressiveTransform(nn.Module):
             self._transform_rows(inputs[s:e], inputs[s:e], ctx, outputs[s:e], logabsdet[s:e], inverse=False)
         return outputs, logabsdet
 
+    def _forward_autograd(self, inputs, context):
+        raise NotImplementedError('this transform has no backward kernels: call under torch.no_grad()')
+
     def inverse(self, inputs, context=None):
         _check_2d(inputs, self.autoregressive_net.initial_layer.in_features)
+        if self._recording(inputs):
+            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
         B, D = inputs.shape
         outputs = torch.zeros_like(inputs)
         logabsdet = torch.zeros(B, dtype=inputs.dtype, device=inputs.device)
@@ -184,6 +194,16 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                              min_derivative=self.min_derivative, want_bins=want_bins)
 
+    def _forward_autograd(self, inputs, context):
+        """Training path: conditioner and spline as autograd.Functions over the backward kernels.  The
+        parameter tensor is materialised here (the backward needs it); inference uses the fused kernel."""
+        from .autograd import RqsFn
+        if context is not None:
+            raise NotImplementedError('context-conditioned training is outside this build')
+        params = self.autoregressive_net(inputs.contiguous(), None)
+        return RqsFn.apply(inputs.contiguous(), params, self.num_bins, self.tails, self.tail_bound,
+                           (self.min_bin_width, self.min_bin_height, self.min_derivative))
+
     def _feature_groups(self):
         """Consecutive features that can be inverted in the same pass.  Feature i (0-based, MADE degree
         i+1) sees hidden units of degree <= i, and input i-1 reaches it only through units of degree
@@ -211,6 +231,8 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         layer and the one fused final-layer tile that holds the features being fixed.  Features not yet
         fixed stay exactly zero in the network input, as in the reference's first pass."""
         net = self.autoregressive_net
+        if self._recording(inputs):
+            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
         if context is not None or not self._fusable():
             return super().inverse(inputs, context)
         D = net.initial_layer.in_features
