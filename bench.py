@@ -72,6 +72,7 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='MADE matrix-core input type')
     ap.add_argument('--cpu-sample', type=int, default=2048)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-bf16', action='store_true', help='skip the secondary bf16-MFMA measurement')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -169,6 +170,22 @@ def main():
                                     'unit': 'GB/s', 'frac': byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                     'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': byts}
         out['kernel_ms'] = {'%s_%dx%d_rows%d' % (k[0], k[1], k[2], k[3]): round(v[1], 4) for k, v in kern.items()}
+        if args.dtype == 'f32' and not args.no_bf16:
+            # secondary figure: the same step with the MADE layers on bf16 MFMA (north_star's 2e-2 contract)
+            nf.set_matmul_dtype('bf16')
+            with torch.no_grad():
+                lp16 = flow.log_prob(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                lp16, _ = step()
+            torch.cuda.synchronize()
+            dt16 = time.perf_counter() - t1
+            nf.set_matmul_dtype('f32')
+            out['bf16_mode'] = {'value': B * args.steps / dt16, 'unit': 'samples/s (this rank)',
+                                'ms_per_step': 1e3 * dt16 / args.steps, 'dtype': 'bf16-mfma/f32-accumulate',
+                                'max_rel_diff_vs_f32_log_prob':
+                                    ((lp16 - logp).abs() / logp.abs().clamp_min(1.0)).max().item()}
         if not args.no_cpu:
             n = min(args.cpu_sample, B)
             v, cores, err = cpu_baseline(sd_cpu, x[:n].cpu(), logp[:n].cpu(), reps=3)

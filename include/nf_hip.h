@@ -53,7 +53,9 @@ int nf_made_ktab_len(int out);
 
 /* Fold `mask` (NULL = dense layer) into row-major W[out,in], zero-pad to whole tiles, convert to
  * `dtype`, and record per 128-row tile the range of 32-wide K tiles holding unmasked weights.
- * Replaces the per-call `self.weight * self.mask` of made.py:152; run once per weight update. */
+ * Replaces the per-call `self.weight * self.mask` of made.py:152; run once per weight update.
+ * ktab == NULL re-folds the weights only and leaves the caller's table alone (the mask, hence the
+ * table, does not change between optimizer steps); the same holds for nf_made_pack_t / nf_made_rqs_pack. */
 int nf_made_pack(const float* W, const float* mask, int out, int in, int dtype,
                  void* packed, int32_t* ktab, void* stream);
 

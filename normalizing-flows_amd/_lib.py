@@ -141,36 +141,46 @@ class PackedLinear:
     """Device buffers produced by nf_made_pack for one [out,in] layer."""
     __slots__ = ('out', 'inp', 'dtype', 'packed', 'ktab', 'bias')
 
-    def __init__(self, weight, mask, bias, dtype=NF_DTYPE_F32):
+    def __init__(self, weight, mask, bias, dtype=NF_DTYPE_F32, reuse=None):
+        """`reuse`: a previous pack of the same layer (same mask, dtype, device): its buffers and K-tile
+        table are kept and only the weights are re-folded (the per-optimizer-step path)."""
         lib = load()
         w = _dev(weight.detach().contiguous(), 'weight')
         m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
         self.out, self.inp = int(w.shape[0]), int(w.shape[1])
         self.dtype = dtype
-        nbytes = lib.nf_made_packed_bytes(self.out, self.inp, dtype)
-        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        self.ktab = torch.empty(lib.nf_made_ktab_len(self.out), dtype=torch.int32, device=w.device)
+        fresh = reuse is None or reuse.dtype != dtype or reuse.packed.device != w.device
+        if fresh:
+            nbytes = lib.nf_made_packed_bytes(self.out, self.inp, dtype)
+            self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            self.ktab = torch.empty(lib.nf_made_ktab_len(self.out), dtype=torch.int32, device=w.device)
+        else:
+            self.packed, self.ktab = reuse.packed, reuse.ktab
         self.bias = None if bias is None else _dev(bias.detach().contiguous(), 'bias')
         with torch.cuda.device(w.device):
             _check(lib.nf_made_pack(w.data_ptr(), _ptr(m), self.out, self.inp, dtype, self.packed.data_ptr(),
-                                    self.ktab.data_ptr(), _stream()), 'nf_made_pack')
+                                    self.ktab.data_ptr() if fresh else None, _stream()), 'nf_made_pack')
 
 
 class PackedLinearT:
     """Transposed pack (nf_made_pack_t) for the input-gradient GEMM of one [out,in] layer."""
     __slots__ = ('out', 'inp', 'dtype', 'packed', 'ktab')
 
-    def __init__(self, weight, mask, dtype=NF_DTYPE_F32):
+    def __init__(self, weight, mask, dtype=NF_DTYPE_F32, reuse=None):
         lib = load()
         w = _dev(weight.detach().contiguous(), 'weight')
         m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
         self.out, self.inp, self.dtype = int(w.shape[0]), int(w.shape[1]), dtype
-        self.packed = torch.empty(lib.nf_made_packed_bytes(self.inp, self.out, dtype), dtype=torch.uint8,
-                                  device=w.device)
-        self.ktab = torch.empty(lib.nf_made_ktab_len(self.inp), dtype=torch.int32, device=w.device)
+        fresh = reuse is None or reuse.dtype != dtype or reuse.packed.device != w.device
+        if fresh:
+            self.packed = torch.empty(lib.nf_made_packed_bytes(self.inp, self.out, dtype), dtype=torch.uint8,
+                                      device=w.device)
+            self.ktab = torch.empty(lib.nf_made_ktab_len(self.inp), dtype=torch.int32, device=w.device)
+        else:
+            self.packed, self.ktab = reuse.packed, reuse.ktab
         with torch.cuda.device(w.device):
             _check(lib.nf_made_pack_t(w.data_ptr(), _ptr(m), self.out, self.inp, dtype, self.packed.data_ptr(),
-                                      self.ktab.data_ptr(), _stream()), 'nf_made_pack_t')
+                                      self.ktab.data_ptr() if fresh else None, _stream()), 'nf_made_pack_t')
 
 
 def masked_linear_bwd_input(grad_y, plt, gate=None):

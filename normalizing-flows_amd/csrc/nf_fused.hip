@@ -429,7 +429,7 @@ extern "C" size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, in
 
 extern "C" int nf_made_rqs_pack(const float* W, const float* mask, const float* bias, int features, int in, int K,
                                 int tails, int dtype, void* packed, int32_t* ktab, float* bias_packed, void* stream) {
-    if (!W || !packed || !ktab || !bias_packed) return NF_ERR_NULL;
+    if (!W || !packed || !bias_packed) return NF_ERR_NULL;     // ktab == NULL: keep the caller's table
     if (features <= 0 || in <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
     if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
@@ -443,7 +443,7 @@ extern "C" int nf_made_rqs_pack(const float* W, const float* mask, const float* 
     else
         hipLaunchKernelGGL(pack_fused_kernel<__bf16>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
                            total, (__bf16*)packed, bias_packed);
-    hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, fpt * P, ktab);
+    if (ktab) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, fpt * P, ktab);
     return nf_launch_status();
 }
 

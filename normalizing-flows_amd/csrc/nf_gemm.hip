@@ -598,7 +598,7 @@ extern "C" int nf_made_ktab_len(int out) { return out <= 0 ? 0 : 2 * n_tiles_of(
 
 static int pack_impl(const float* W, const float* mask, int out, int in, int64_t sn, int64_t sk, int dtype,
                      void* packed, int32_t* ktab, void* stream) {
-    if (!W || !packed || !ktab) return NF_ERR_NULL;
+    if (!W || !packed) return NF_ERR_NULL;       // ktab == NULL: the mask is unchanged, keep the caller's table
     if (out <= 0 || in <= 0) return NF_ERR_SHAPE;
     if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
     hipStream_t s = (hipStream_t)stream;
@@ -611,7 +611,7 @@ static int pack_impl(const float* W, const float* mask, int out, int in, int64_t
     else
         hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, sn, sk, kpad, total,
                            (__bf16*)packed);
-    hipLaunchKernelGGL(ktab_kernel, dim3(n_tiles_of(out)), dim3(256), 0, s, mask, out, in, sn, sk, ktab);
+    if (ktab) hipLaunchKernelGGL(ktab_kernel, dim3(n_tiles_of(out)), dim3(256), 0, s, mask, out, in, sn, sk, ktab);
     return nf_launch_status();
 }
 

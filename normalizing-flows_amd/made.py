@@ -60,11 +60,14 @@ class _PackedMixin:
 
     def _packed_linear(self):
         mask = getattr(self, 'mask', None)
+        mkey = None if mask is None else (mask._version, mask.data_ptr())
         key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
-               get_matmul_dtype(), self.weight.device)
+               get_matmul_dtype(), self.weight.device, mkey)
         cached = getattr(self, '_pack_cache', None)
         if cached is None or cached[0] != key:
-            pl = _lib.PackedLinear(self.weight, mask, self.bias, _MATMUL_DTYPE[get_matmul_dtype()])
+            same_mask = cached is not None and cached[0][-1] == mkey      # then the K-tile table is still valid
+            pl = _lib.PackedLinear(self.weight, mask, self.bias, _MATMUL_DTYPE[get_matmul_dtype()],
+                                   reuse=cached[1] if same_mask else None)
             object.__setattr__(self, '_pack_cache', (key, pl))
             cached = self._pack_cache
         return cached[1]
@@ -83,10 +86,13 @@ class _PackedMixin:
 
     def _packed_linear_t(self):
         """Transposed pack for the input-gradient GEMM, cached like the forward pack."""
-        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        mask = getattr(self, 'mask', None)
+        mkey = None if mask is None else (mask._version, mask.data_ptr())
+        key = (self.weight._version, self.weight.data_ptr(), self.weight.device, mkey)
         cached = getattr(self, '_pack_t_cache', None)
         if cached is None or cached[0] != key:
-            plt = _lib.PackedLinearT(self.weight, getattr(self, 'mask', None), _lib.NF_DTYPE_F32)
+            same_mask = cached is not None and cached[0][-1] == mkey
+            plt = _lib.PackedLinearT(self.weight, mask, _lib.NF_DTYPE_F32, reuse=cached[1] if same_mask else None)
             object.__setattr__(self, '_pack_t_cache', (key, plt))
             cached = self._pack_t_cache
         return cached[1]

@@ -59,3 +59,30 @@ def test_two_rank_log_likelihood_reduction(tmp_path, n):
     want = O.flow_log_prob([lambda u: O.rq_autoregressive_forward(sd, u, K, 3.0)], x).double().mean().item()
     assert abs(got['mean'] - want) < 1e-5 * max(1.0, abs(want))
     assert (got['lo'], got['hi']) == (0, (n + 1) // 2)
+
+
+def _grad_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from normalizing_flows_amd import parallel
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 300, 7, 1024)]
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        nb = parallel.allreduce_gradients(params, bucket_bytes=1024)
+        if rank == 0:
+            torch.save({'grads': [p.grad.clone() for p in params], 'buckets': nb}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    out = str(tmp_path / 'g0.pt')
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_grad_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got['buckets'] >= 2                      # several buckets in flight
+    for i, g in enumerate(got['grads']):
+        assert torch.allclose(g, torch.full_like(g, 1.5 * (i + 1)))      # mean of ranks' (1, 2) x (i+1)
