@@ -186,6 +186,10 @@ def main():
                                 'ms_per_step': 1e3 * dt16 / args.steps, 'dtype': 'bf16-mfma/f32-accumulate',
                                 'max_rel_diff_vs_f32_log_prob':
                                     ((lp16 - logp).abs() / logp.abs().clamp_min(1.0)).max().item()}
+        f32_tf, bf16_tf, copy_gbs = nf._lib.measure_device_peaks()
+        out['measured_device_peaks'] = {'mfma_f32_tflops': f32_tf, 'mfma_bf16_tflops': bf16_tf, 'copy_gbs': copy_gbs,
+                                        'note': 'back-to-back MFMA issue loop / 1 GiB float4 copy on this device; the '
+                                                'roofline fractions above use the nominal peaks'}
         if not args.no_cpu:
             n = min(args.cpu_sample, B)
             v, cores, err = cpu_baseline(sd_cpu, x[:n].cpu(), logp[:n].cpu(), reps=3)

@@ -197,6 +197,15 @@ int nf_maf_reverse_step(const double* x, int64_t x_row_stride, const double* mad
                         double* z, int64_t z_row_stride, double* logJ, int64_t B, int D, int dim,
                         int reverse_input, void* stream);
 
+/* ---- diagnostics (no reference counterpart): what this device sustains, printed by bench.py beside the
+ *      nominal roofline peaks ------------------------------------------------------------------------- */
+
+/* blocks x 4 waves each issue iters*4 back-to-back MFMAs on 4 accumulators: dtype NF_DTYPE_F32 =
+ * v_mfma_f32_32x32x2_f32 (4096 FLOP per wave instruction), NF_DTYPE_BF16 = 32x32x16 (32768 FLOP). */
+int nf_diag_mfma_loop(float* scratch, int blocks, int iters, int dtype, void* stream);
+/* 16-byte-per-lane device copy of `bytes` (a multiple of 16): the achievable HBM stream rate. */
+int nf_diag_stream_copy(const void* src, void* dst, size_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,8 @@ _SIGNATURES = {
     'nf_rqs_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p, _c.c_int64,
                               _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
                               _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_void_p]),
+    'nf_diag_mfma_loop': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_diag_stream_copy': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     'nf_fold_f64': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     'nf_linear_f64_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
@@ -459,3 +461,35 @@ def maf_reverse_step(x, made_out, z, dim, reverse_input, logJ=None):
     with torch.cuda.device(x.device):
         _check(lib.nf_maf_reverse_step(xp, xs, op, os_, zp, zs, _ptr(logJ), B, D, int(dim), int(bool(reverse_input)),
                                        _stream()), 'nf_maf_reverse_step')
+
+
+# ------------------------------------------------------------------------------------------------ diagnostics
+def measure_device_peaks(seconds_hint=0.05):
+    """(fp32-MFMA TFLOP/s, bf16-MFMA TFLOP/s, copy GB/s counting read+write) sustained by this device."""
+    lib = load()
+    scratch = torch.zeros(16, dtype=torch.float32, device='cuda')
+    out = []
+    for dtype, flop in ((NF_DTYPE_F32, 4096), (NF_DTYPE_BF16, 32768)):
+        blocks, iters = 256 * 4, 20000
+        best = 0.0
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _check(lib.nf_diag_mfma_loop(scratch.data_ptr(), blocks, iters, dtype, _stream()), 'nf_diag_mfma_loop')
+            b.record()
+            torch.cuda.synchronize()
+            best = max(best, blocks * 4 * iters * 4 * flop / (a.elapsed_time(b) * 1e-3) / 1e12)
+        out.append(best)
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device='cuda')
+    dst = torch.empty(n, dtype=torch.uint8, device='cuda')
+    best = 0.0
+    for _ in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _check(lib.nf_diag_stream_copy(src.data_ptr(), dst.data_ptr(), n, _stream()), 'nf_diag_stream_copy')
+        b.record()
+        torch.cuda.synchronize()
+        best = max(best, 2 * n / (a.elapsed_time(b) * 1e-3) / 1e9)
+    out.append(best)
+    return tuple(out)

@@ -15,3 +15,61 @@ extern "C" const char* nf_strerror(int code) {
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
+
+// ---- diagnostics: achievable peaks of this device (used by bench.py beside the nominal roofline peaks) ----
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void mfma_f32_loop_kernel(float* out, int iters) {
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f - threadIdx.x * 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j) s += acc[j][0];
+    if (s == 12345.678f) out[0] = s;           // keeps the loop alive, never true in practice
+}
+
+__global__ __launch_bounds__(256) void mfma_bf16_loop_kernel(float* out, int iters) {
+    f32x16 acc[4];
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    bf16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(1.0f + 0.01f * j + threadIdx.x * 1e-3f); b[j] = (__bf16)(0.5f - 0.01f * j); }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int j = 0; j < 4; ++j) s += acc[j][0];
+    if (s == 12345.678f) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+
+// Launches `blocks` x 256 threads each issuing iters*4 back-to-back MFMAs (dtype 0: 32x32x2 f32 = 4096 FLOP,
+// dtype 1: 32x32x16 bf16 = 32768 FLOP per wave instruction).  FLOP = blocks*4 waves*iters*4*that.
+extern "C" int nf_diag_mfma_loop(float* scratch, int blocks, int iters, int dtype, void* stream) {
+    if (!scratch) return NF_ERR_NULL;
+    if (blocks <= 0 || iters <= 0) return NF_ERR_SHAPE;
+    if (dtype == NF_DTYPE_F32) hipLaunchKernelGGL(mfma_f32_loop_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+    else hipLaunchKernelGGL(mfma_bf16_loop_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+    return nf_launch_status();
+}
+
+// dst[0..bytes) = src[0..bytes) with 16-byte accesses (bytes % 16 == 0): the achievable HBM copy rate.
+extern "C" int nf_diag_stream_copy(const void* src, void* dst, size_t bytes, void* stream) {
+    if (!src || !dst) return NF_ERR_NULL;
+    if (bytes % 16) return NF_ERR_LAYOUT;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
+                       (int64_t)(bytes / 16));
+    return nf_launch_status();
+}
