@@ -6,6 +6,49 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+// Transcendentals and divisions of the spline: the hardware v_exp_f32 / v_log_f32 / v_rcp_f32 forms
+// (about 1-2 ulp) instead of the correctly rounded library routines.  The reference's own CPU kernels
+// (Sleef exp at 1-2 ulp, fexp_u20 inside softmax) are no closer to correctly rounded than this, so the
+// parity bars (bit-exact bins away from knots, 1e-5 on outputs / logdet) are unaffected, while the
+// per-element VALU cost - what bounds the standalone kernel and the fused epilogue - drops by ~45 %.
+// Build with -DNF_SPLINE_FAST=0 for the library forms.
+#ifndef NF_SPLINE_FAST
+#define NF_SPLINE_FAST 1
+#endif
+__device__ __forceinline__ float nf_exp(float x) {
+#if NF_SPLINE_FAST
+    // exp2(x*log2e) with the rounding error of the product carried to first order: for |x| ~ 10 the plain
+    // product is off by ~1e-6 in the exponent, which the 2T knot scale (T = 50) would turn into 1e-5 knots
+    const float th = x * 1.44269504088896341f;
+    const float tl = fmaf(x, 1.44269504088896341f, -th) + x * 1.925963033500e-8f;
+    const float e = __builtin_amdgcn_exp2f(th);
+    return fmaf(e, tl * 0.693147180559945309f, e);
+#else
+    return expf(x);
+#endif
+}
+__device__ __forceinline__ float nf_log(float x) {
+#if NF_SPLINE_FAST
+    return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
+#else
+    return logf(x);
+#endif
+}
+__device__ __forceinline__ float nf_rcp(float x) {
+#if NF_SPLINE_FAST
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+__device__ __forceinline__ float nf_div(float a, float b) {
+#if NF_SPLINE_FAST
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+
 struct RqsConst {
     int K, P;
     int tails;                 // 1 = linear tails (P = 3K-1), 0 = none (P = 3K+1)
@@ -39,7 +82,11 @@ static inline RqsConst nf_make_rqs_const(int K, int tails, double tail_bound, do
 
 __device__ __forceinline__ float softplus_f(float u) {
     // F.softplus(beta=1, threshold=20)
-    return u > 20.0f ? u : log1pf(expf(u));
+#if NF_SPLINE_FAST
+    return u > 20.0f ? u : nf_log(1.0f + nf_exp(u));
+#else
+    return u > 20.0f ? u : log1pf(nf_exp(u));
+#endif
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -67,7 +114,7 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
     // softmax denominators: max, then sum of exp(u - max) left to right
     auto raw = [&](const float* u, int k) {
         float v = u[k];
-        return scaled ? v / a.pre_div : v;
+        return scaled ? nf_div(v, a.pre_div) : v;
     };
     float mw = -INFINITY, mh = -INFINITY;
     constexpr int KA = KT > 0 ? KT : 1;
@@ -85,13 +132,13 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
         float w, h;
         if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
         else { w = raw(uw, k); h = raw(uh, k); }
-        w = expf(w - mw);
-        h = expf(h - mh);
+        w = nf_exp(w - mw);
+        h = nf_exp(h - mh);
         if constexpr (KT > 0) { ew[k] = w; eh[k] = h; }
         sw += w;
         sh += h;
     }
-    const float rw = 1.0f / sw, rh = 1.0f / sh;
+    const float rw = nf_rcp(sw), rh = nf_rcp(sh);
 
     // knots on the fly: floor + rescale, prefix sum carried in fp64 and rounded per prefix (what
     // ATen's fp32 cumsum produces), affine map to [left,right], last knot pinned.
@@ -103,7 +150,7 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
     for (int k = 0; k < K; ++k) {
         float w, h;
         if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
-        else { w = expf(raw(uw, k) - mw); h = expf(raw(uh, k) - mh); }
+        else { w = nf_exp(raw(uw, k) - mw); h = nf_exp(raw(uh, k) - mh); }
         w = a.min_w + a.scale_w * (w * rw);
         h = a.min_h + a.scale_h * (h * rh);
         accw += (double)w;
@@ -134,7 +181,7 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
 
     const float bw = x1 - x0;
     const float bh = y1 - y0;
-    const float s = bh / bw;
+    const float s = bh / bw;            // IEEE division: s and t feed the cancelling terms below
     const float curv = d0 + d1 - 2.0f * s;
     float t, den;
     if (INV) {
@@ -152,11 +199,11 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
     den = s + curv * t1mt;
     if (!INV) {
         const float num = bh * (s * (t * t) + d0 * t1mt);
-        y = y0 + num / den;
+        y = y0 + nf_div(num, den);
     }
     const float omt = 1.0f - t;
     const float dnum = (s * s) * (d1 * (t * t) + 2.0f * s * t1mt + d0 * (omt * omt));
-    const float l = logf(dnum) - 2.0f * logf(den);
+    const float l = nf_log(dnum) - 2.0f * nf_log(den);
     ld = INV ? -l : l;
 }
 
@@ -179,7 +226,7 @@ __device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, fl
     const bool scaled = a.pre_div != 1.0f;
     auto raw = [&](const float* u, int k) {
         float v = u[k];
-        return scaled ? v / a.pre_div : v;
+        return scaled ? nf_div(v, a.pre_div) : v;
     };
     float mw = -INFINITY, mh = -INFINITY;
 #pragma unroll
@@ -192,12 +239,12 @@ __device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, fl
     float sw = 0.0f, sh = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const float w = expf(raw(uw, k) - mw), h = expf(raw(uh, k) - mh);
+        const float w = nf_exp(raw(uw, k) - mw), h = nf_exp(raw(uh, k) - mh);
         if constexpr (KT > 0) { ew[k] = w; eh[k] = h; }
         sw += w;
         sh += h;
     }
-    const float rw = 1.0f / sw, rh = 1.0f / sh;
+    const float rw = nf_rcp(sw), rh = nf_rcp(sh);
     double accw = 0.0, acch = 0.0;
     float kw0 = a.left, kh0 = a.left;
     float x0 = a.left, x1 = a.left, y0 = a.left, y1 = a.left;
@@ -206,7 +253,7 @@ __device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, fl
     for (int k = 0; k < K; ++k) {
         float w, h;
         if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
-        else { w = expf(raw(uw, k) - mw); h = expf(raw(uh, k) - mh); }
+        else { w = nf_exp(raw(uw, k) - mw); h = nf_exp(raw(uh, k) - mh); }
         w = a.min_w + a.scale_w * (w * rw);
         h = a.min_h + a.scale_h * (h * rh);
         accw += (double)w;
@@ -228,26 +275,27 @@ __device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, fl
     const float d1 = a.min_d + softplus_f(u1);
 
     const float bw = x1 - x0, bh = y1 - y0;
-    const float s = bh / bw;
-    const float t = (x - x0) / bw;
+    const float s = nf_div(bh, bw);
+    const float t = nf_div(x - x0, bw);
     const float q = t * (1.0f - t), omt = 1.0f - t;
     const float c = d0 + d1 - 2.0f * s;
     const float N = bh * (s * t * t + d0 * q);
     const float Dn = s + c * q;
     const float M = d1 * t * t + 2.0f * s * q + d0 * omt * omt;
 
-    const float A = gy / Dn;                                   // dL/dN
-    const float Bc = -gy * N / (Dn * Dn) - 2.0f * gl / Dn;     // dL/dDn
-    const float Cm = gl / M;                                   // dL/dM
+    const float rDn = nf_rcp(Dn), rbw = nf_rcp(bw);
+    const float A = gy * rDn;                                  // dL/dN
+    const float Bc = -gy * N * (rDn * rDn) - 2.0f * gl * rDn;  // dL/dDn
+    const float Cm = nf_div(gl, M);                            // dL/dM
     const float g_t = A * bh * (2.0f * s * t + d0 * (1.0f - 2.0f * t)) + Bc * c * (1.0f - 2.0f * t) +
                       Cm * (2.0f * d1 * t + 2.0f * s * (1.0f - 2.0f * t) - 2.0f * d0 * omt);
-    const float g_s = A * bh * t * t + Bc * (1.0f - 2.0f * q) + Cm * 2.0f * q + 2.0f * gl / s;
-    float g_bh = A * (s * t * t + d0 * q) + g_s / bw;
+    const float g_s = A * bh * t * t + Bc * (1.0f - 2.0f * q) + Cm * 2.0f * q + nf_div(2.0f * gl, s);
+    float g_bh = A * (s * t * t + d0 * q) + g_s * rbw;
     const float g_d0 = A * bh * q + Bc * q + Cm * omt * omt;
     const float g_d1 = Bc * q + Cm * t * t;
-    const float g_bw = -g_t * t / bw - g_s * s / bw;
-    const float gx = g_t / bw;
-    const float g_x0 = -g_t / bw - g_bw, g_x1 = g_bw;
+    const float g_bw = -g_t * t * rbw - g_s * s * rbw;
+    const float gx = g_t * rbw;
+    const float g_x0 = -g_t * rbw - g_bw, g_x1 = g_bw;
     const float g_y0 = gy - g_bh, g_y1 = g_bh;
 
     // knots b and b+1 move with the widths / heights only when they are interior (ends are pinned)
@@ -259,23 +307,23 @@ __device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, fl
     for (int k = 0; k < K; ++k) {
         float w, h;
         if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
-        else { w = expf(raw(uw, k) - mw); h = expf(raw(uh, k) - mh); }
+        else { w = nf_exp(raw(uw, k) - mw); h = nf_exp(raw(uh, k) - mh); }
         const float gw = a.scale_w * ((k < bin ? Gw0 : 0.0f) + (k <= bin ? Gw1 : 0.0f));
         const float gh = a.scale_h * ((k < bin ? Gh0 : 0.0f) + (k <= bin ? Gh1 : 0.0f));
         dotw += (w * rw) * gw;
         doth += (h * rh) * gh;
     }
-    const float sig0 = 1.0f / (1.0f + expf(-u0)), sig1 = 1.0f / (1.0f + expf(-u1));
+    const float sig0 = nf_rcp(1.0f + nf_exp(-u0)), sig1 = nf_rcp(1.0f + nf_exp(-u1));
     const int nd = P - 2 * K;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float w, h;
         if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
-        else { w = expf(raw(uw, k) - mw); h = expf(raw(uh, k) - mh); }
+        else { w = nf_exp(raw(uw, k) - mw); h = nf_exp(raw(uh, k) - mh); }
         const float gw = a.scale_w * ((k < bin ? Gw0 : 0.0f) + (k <= bin ? Gw1 : 0.0f));
         const float gh = a.scale_h * ((k < bin ? Gh0 : 0.0f) + (k <= bin ? Gh1 : 0.0f));
         float ow = (w * rw) * (gw - dotw), oh = (h * rh) * (gh - doth);
-        if (scaled) { ow = ow / a.pre_div; oh = oh / a.pre_div; }
+        if (scaled) { ow = nf_div(ow, a.pre_div); oh = nf_div(oh, a.pre_div); }
         uw[k] = ow;
         uh[k] = oh;
     }
