@@ -65,7 +65,9 @@ __device__ __forceinline__ void tile_of_block(const FusedArgs& g, int64_t& tm, i
     const int64_t gm = min((int64_t)GROUP_M, g.m_tiles - first_m);
     const int64_t in = wg - grp * per_group;
     tm = first_m + in % gm;
-    tn = (int)(in / gm) + g.tn0;
+    // heaviest column tiles first: with triangular masks the K extent grows with the tile index, and
+    // starting the long workgroups early leaves the short ones to fill the tail of the launch
+    tn = g.n_tiles - 1 - (int)(in / gm) + g.tn0;
 }
 
 // ---- operand staging (fp32 / bf16 flavours share the kernel skeleton through this trait) -------------

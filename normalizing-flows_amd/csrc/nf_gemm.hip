@@ -64,7 +64,9 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int64_t& tm, in
     const int64_t gm = min((int64_t)GROUP_M, g.m_tiles - first_m);
     const int64_t in = wg - grp * per_group;
     tm = first_m + in % gm;
-    tn = (int)(in / gm) + g.tn0;
+    // heaviest column tiles first: with triangular masks the K extent grows with the tile index, and
+    // starting the long workgroups early leaves the short ones to fill the tail of the launch
+    tn = g.n_tiles - 1 - (int)(in / gm) + g.tn0;
 }
 
 // load_one only issues the loads; everything that consumes a loaded value lives in store_one so that
