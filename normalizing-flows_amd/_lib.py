@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnf_hip.so')
+# NF_HIP_LIB: another build of the same library (kernel A/B experiments); never a different implementation
+LIB_PATH = os.environ.get('NF_HIP_LIB') or os.path.join(_HERE, 'libnf_hip.so')
 
 NF_DTYPE_F32 = 0
 NF_DTYPE_BF16 = 1

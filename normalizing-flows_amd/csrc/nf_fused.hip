@@ -27,7 +27,8 @@ constexpr int FM = 128, FN = 256;       // block tile
 constexpr int FT = 512;                 // threads
 constexpr int BK = 32, LDA = BK + 4;    // fp32 staging: K tile and padded LDS row (floats)
 constexpr int BK16 = 64, LDA16 = BK16 + 8;
-constexpr int EP_LD = 257;              // epilogue tile row stride (floats): odd => conflict-free per-lane rows
+constexpr int LDT = 68;                 // epilogue tile: [256 parameter columns][64 samples + 4], column-major so that
+                                        // a lane's 4 consecutive accumulator rows go out as one ds_write_b128
 constexpr int GROUP_M = 8;
 
 struct FusedArgs {
@@ -228,10 +229,10 @@ struct Stage<true> {
 template <bool BF16, int KT, bool INV>
 __global__ __launch_bounds__(FT, 4) void made_rqs_kernel(const FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    // [0, 64*EP_LD*4): operand staging during the K loop, then the epilogue parameter tile
+    // [0, FN*LDT*4): operand staging during the K loop, then the epilogue parameter tile
     float* tile = (float*)lds;
-    float* xs = tile + 64 * EP_LD;                   // [128][fpt] inputs, overwritten by outputs
-    float* ldp = xs + FM * g.fpt;                    // [64][fpt] per-element logdets of one half
+    float* xs = tile + FN * LDT;                     // [128][fpt] inputs, overwritten by outputs
+    float* ldp = xs + FM * g.fpt;                    // [8 waves][128] logdet sums of the features a wave evaluated
 
     int64_t tm;
     int tn;
@@ -255,68 +256,99 @@ __global__ __launch_bounds__(FT, 4) void made_rqs_kernel(const FusedArgs g) {
     const int kq = Stage<BF16>::kBK / 32;
     const int kt_begin = g.ktab[2 * tn] / kq, kt_end = (g.ktab[2 * tn + 1] + kq - 1) / kq;
 
+    // accumulators start at the bias of their column (a lane's 16 values of one MFMA tile share a column)
     f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+        const float bv = g.bias[tn * FN + wc * 64 + j * 32 + (lane & 31)];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
 
+#ifdef NF_STAMP
+    long long tA = 0, tS = 0, tB = 0, tL = 0, tM = 0, tE = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, t0 = clock64(), t1;
+    const long long tstart = t0;
+#define STAMP(v) __builtin_amdgcn_sched_barrier(0); t1 = clock64(); v += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0);
+#else
+#define STAMP(v)
+#endif
     Stage<BF16> st;
     st.init(g, lds, m0, tn, tid);
     if (kt_begin < kt_end) st.load(kt_begin);
+    STAMP(tL)
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         __syncthreads();
+        STAMP(tA)
         st.store(kt);
+        STAMP(tS)
         __syncthreads();
+        STAMP(tB)
         st.load(min(kt + 1, kt_end - 1));            // prefetch under the MFMAs (last one is a re-read)
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(tL)
         st.mma(lds, wr, wc, lane, acc);
+        STAMP(tM)
     }
 
     // ---- epilogue: two halves of 64 rows through the LDS tile ---------------------------------------
+#ifdef NF_EPI_PRIO
+    __builtin_amdgcn_s_setprio(NF_EPI_PRIO);
+#endif
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         __syncthreads();                             // staging / previous half fully consumed
+        STAMP(e0)
         if (wr == half) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int col = wc * 64 + j * 32 + (lane & 31);
-                const float bv = g.bias[tn * FN + col];
+                float* tp = tile + (wc * 64 + j * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        tile[row * EP_LD + col] = acc[i][j][r] + bv;
-                    }
+                    for (int q = 0; q < 4; ++q)      // rows i*32 + 8q + 4*(lane>>5) + 0..3
+                        *reinterpret_cast<float4*>(tp + i * 32 + 8 * q) =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
             }
         }
         __syncthreads();
+        STAMP(e1)
+        float lsum = 0.f;                            // lane = sample row, wave-uniform feature
         for (int e = tid; e < 64 * fv; e += FT) {
-            const int f = e >> 6, row = e & 63;
-            const int r = half * 64 + row;
+            const int f = e >> 6;
+            const int r = half * 64 + lane;
             float yv, ld;
             int bin;
-            rqs_eval<KT, INV>(tile + row * EP_LD + f * P, xs[r * fpt + f], g.c, yv, ld, bin);
+            rqs_eval<KT, INV, LDT>(tile + f * P * LDT + lane, xs[r * fpt + f], g.c, yv, ld, bin);
             xs[r * fpt + f] = yv;
-            ldp[row * fpt + f] = ld;
+            lsum += ld;
+#ifndef NF_STAMP
             if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + f] = bin;
+#endif
         }
-        __syncthreads();
-        if (tid < 64) {
-            float s = 0.f;
-            for (int f = 0; f < fv; ++f) s += ldp[tid * fpt + f];
-            const int64_t r = m0 + half * 64 + tid;
-            if (r < g.M) g.partial[(int64_t)tn * g.M + r] = s;
-        }
+        ldp[wave * FM + half * 64 + lane] = lsum;
+        STAMP(e2)
     }
     __syncthreads();
+    if (tid < FM) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < FT / 64; ++w) s += ldp[w * FM + tid];          // fixed order: deterministic
+        if (m0 + tid < g.M) g.partial[(int64_t)tn * g.M + m0 + tid] = s;
+    }
+    STAMP(e3)
     for (int i = tid; i < FM * fpt; i += FT) {
         const int r = i / fpt, f = i - r * fpt;
         if (m0 + r < g.M && f < fv) g.y[(m0 + r) * g.ldy + f0 + f] = xs[i];
     }
+#ifdef NF_STAMP
+    STAMP(tE)
+    if (g.bins && lane == 0) {
+        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * 8 + wave) * 16;
+        dbg[0] = tA; dbg[1] = tS; dbg[2] = tB; dbg[3] = tL; dbg[4] = tM; dbg[5] = tE; dbg[6] = tstart; dbg[7] = kt_end - kt_begin; dbg[8] = e0; dbg[9] = e1; dbg[10] = e2; dbg[11] = e3;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ partial, int n_tiles, int64_t M,
@@ -382,7 +414,7 @@ inline bool fused_supported(int K, int tails) {   // (and the hidden width must 
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
     return K >= 4 && K <= 32 && P <= FN;
 }
-inline size_t lds_bytes(int fpt) { return sizeof(float) * ((size_t)64 * EP_LD + (size_t)FM * fpt + (size_t)64 * fpt); }
+inline size_t lds_bytes(int fpt) { return sizeof(float) * ((size_t)FN * LDT + (size_t)FM * fpt + (size_t)FM * (FT / 64)); }
 
 template <bool BF16, int KT, bool INV>
 int launch_one(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {

@@ -95,8 +95,9 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Evaluates one element.  p points at its P parameters in LDS.
-template <int KT, bool INV>
+// Evaluates one element.  p points at its P parameters in LDS, STRIDE floats apart (1 = contiguous;
+// the fused kernel keeps its parameter tile feature-major, one row of samples per parameter).
+template <int KT, bool INV, int STRIDE = 1>
 __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, const RqsConst& a,
                                          float& y, float& ld, int& bin) {
     const int K = KT > 0 ? KT : a.K;
@@ -107,13 +108,13 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
         return;
     }
     const float* uw = p;
-    const float* uh = p + K;
-    const float* ud = p + 2 * K;
+    const float* uh = p + K * STRIDE;
+    const float* ud = p + 2 * K * STRIDE;
     const bool scaled = a.pre_div != 1.0f;
 
     // softmax denominators: max, then sum of exp(u - max) left to right
     auto raw = [&](const float* u, int k) {
-        float v = u[k];
+        float v = u[k * STRIDE];
         return scaled ? nf_div(v, a.pre_div) : v;
     };
     float mw = -INFINITY, mh = -INFINITY;
@@ -170,11 +171,11 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
     // slopes at the two knots of the bin
     float u0, u1;
     if (a.tails) {
-        u0 = bin == 0 ? a.tail_const : ud[bin - 1];
-        u1 = bin == K - 1 ? a.tail_const : ud[bin];
+        u0 = bin == 0 ? a.tail_const : ud[(bin - 1) * STRIDE];
+        u1 = bin == K - 1 ? a.tail_const : ud[bin * STRIDE];
     } else {
-        u0 = ud[bin];
-        u1 = ud[bin + 1];
+        u0 = ud[bin * STRIDE];
+        u1 = ud[(bin + 1) * STRIDE];
     }
     const float d0 = a.min_d + softplus_f(u0);
     const float d1 = a.min_d + softplus_f(u1);
