@@ -25,10 +25,11 @@ with torch.no_grad():
     out = t._transform_rows(x, x, None, torch.empty_like(x), None, False, want_bins=True)
 torch.cuda.synchronize()
 bins = out[2]
-m_tiles = (B + 127) // 128
+m_tiles = (B + 63) // 64
+WAVES = 4
 n_tiles = (D + 10) // 11
 grid = m_tiles * n_tiles
-s = bins.view(-1).view(torch.int64)[: grid * 128].view(grid, 8, 16).cpu().double()
+s = bins.view(-1).view(torch.int64)[: grid * WAVES * 16].view(grid, WAVES, 16).cpu().double()
 kt = s[:, :, 7]
 names = ['barA', 'store', 'barB', 'load', 'mma', 'epi', '', '', 'e0bar', 'e1wr', 'e2eval', 'e3sum']
 tot = s[:, :, :6].sum(2) + s[:, :, 8:12].sum(2)
@@ -38,13 +39,13 @@ for i, n in enumerate(names):
         continue
     print('%6s total %6.1f%%   per k-tile %8.1f cycles' % (n, 100 * s[:, :, i].sum().item() / tot.sum().item(),
                                                           (s[:, :, i] / kt.clamp_min(1)).mean().item()))
-full = kt[:, 0] == 16
+full = kt[:, 0] == kt.max()
 print('full-K blocks: %d' % full.sum().item())
 for i, n in enumerate(names):
     if not n:
         continue
-    print('%6s per k-tile (16-tile blocks) %8.1f' % (n, (s[full][:, :, i] / 16).mean().item()))
+    print('%6s per k-tile (16-tile blocks) %8.1f' % (n, (s[full][:, :, i] / kt.max()).mean().item()))
 start = s[:, :, 6]
 print('kernel span cycles', (start.max() - start.min()).item())
-for w in range(8):
+for w in range(WAVES):
     print('wave', w, ' '.join('%s=%.0f' % (n, s[full][:, w, i].mean().item()) for i, n in enumerate(names) if n))

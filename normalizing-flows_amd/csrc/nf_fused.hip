@@ -6,15 +6,18 @@
 //   logabsdet[b]       = sum_d ld[b,d]                                   (helper_functions.py:393-398)
 //
 // The reference materialises `params` ([B, D*P] floats: 72 KB per sample at D=784, K=8), the largest HBM
-// object of the whole path, only to consume it once.  Here a workgroup owns 128 samples x FPT features
+// object of the whole path, only to consume it once.  Here a workgroup owns 64 samples x FPT features
 // (FPT = 256 / P whole features, 11 at P=23, so the 256-column weight tile holds only whole parameter
-// rows), accumulates the 128 x 256 tile on the matrix cores exactly like nf_gemm.hip, drops it into LDS
-// (aliasing the operand staging buffers), and evaluates the spline from there: `params` never reaches
+// rows), accumulates the 64 x 256 tile on the matrix cores, drops it into LDS 32 samples at a time
+// (aliasing the operand staging buffers) and evaluates the spline from there: `params` never reaches
 // HBM.  Per-sample logdet partial sums go to a [n_tiles, B] scratch (4 bytes per sample per tile) that a
 // second tiny kernel adds up in a fixed order - deterministic, no float atomics.
 //
-// 512 threads = 8 waves as 2 (rows) x 4 (cols), 64 x 64 outputs per wave (2x2 MFMA tiles), so the
-// register budget matches nf_gemm.hip; the spline's VALU work runs beside other waves' MFMAs.
+// Occupancy is the design point: 256 threads (one wave per SIMD), 128 VGPRs and ~40 KB of LDS per
+// workgroup put FOUR independent workgroups on a CU.  A workgroup's spline epilogue (VALU, ~20 % of its
+// lifetime) and its barrier phases issue no MFMA; with four barrier domains per SIMD the other three keep
+// the matrix pipe busy meanwhile (measured with the NF_STAMP phase clocks: two 512-thread workgroups per
+// CU left the pipe idle 30 % of the time, benchmarks/diag_stamp.py).
 #include "nf_common.h"
 #include "nf_rqs_eval.h"
 
@@ -23,20 +26,22 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int FM = 128, FN = 256;       // block tile
-constexpr int FT = 512;                 // threads
-constexpr int BK = 32, LDA = BK + 4;    // fp32 staging: K tile and padded LDS row (floats)
-constexpr int BK16 = 64, LDA16 = BK16 + 8;
-constexpr int LDT = 68;                 // epilogue tile: [256 parameter columns][64 samples + 4], column-major so that
-                                        // a lane's 4 consecutive accumulator rows go out as one ds_write_b128
-constexpr int GROUP_M = 8;
+constexpr int FM = 64, FN = 256;        // block tile: 64 samples x 256 parameter columns
+constexpr int FT = 256;                 // threads: 4 waves side by side, 64 x 64 outputs each (2x2 MFMA tiles)
+constexpr int BK = 16, LDA = BK + 4;    // fp32 staging: K tile and padded LDS row (floats)
+constexpr int BK16 = 32, LDA16 = BK16 + 8;   // bf16 staging (elements); both rows are 80 bytes: conflict-free b128
+constexpr int KPAD = 64;                // packed weight rows are padded to this many K elements
+constexpr int HR = 32;                  // epilogue: samples per pass through the LDS parameter tile
+constexpr int LDT = HR + 4;             // parameter tile [columns][HR + 4], column-major: a lane's 4 consecutive
+                                        // accumulator rows go out as one ds_write_b128, conflict-free
+constexpr int GROUP_M = 16;
 
 struct FusedArgs {
     const float* h;          // [M, K] conditioner hidden state
     int64_t ldh;
     const void* w;           // packed [n_tiles*256][kpad] (f32 or bf16)
     int kpad;
-    const int32_t* ktab;     // [n_tiles][2] in 32-wide K tiles
+    const int32_t* ktab;     // [n_tiles][2]: live K range of each column tile in 16-wide K steps
     const float* bias;       // packed [n_tiles*256]
     const float* x;          // [M, D] transform inputs
     int64_t ldx;
@@ -78,17 +83,17 @@ struct Stage;
 template <>
 struct Stage<false> {
     static constexpr int kBK = BK;
-    const float *a0, *a1, *b0, *b1, *b2, *b3;
-    float4 ra0, ra1, rb0, rb1, rb2, rb3;
+    // 16-byte chunks: A 64 rows x 4 = 256 -> 1 per thread, B 256 rows x 4 = 1024 -> 4 per thread
+    const float *a0, *b0, *b1, *b2, *b3;
+    float4 ra0, rb0, rb1, rb2, rb3;
     float *as, *bs;
     int skc, K;
 
     __device__ __forceinline__ void init(const FusedArgs& g, char* lds, int64_t m0, int tn, int tid) {
-        const int srow = tid >> 3;
-        skc = (tid & 7) * 4;
+        const int srow = tid >> 2;
+        skc = (tid & 3) * 4;
         K = g.K;
         a0 = g.h + min(m0 + srow, g.M - 1) * g.ldh;
-        a1 = g.h + min(m0 + srow + 64, g.M - 1) * g.ldh;
         b0 = (const float*)g.w + (int64_t)(tn * FN + srow) * g.kpad + skc;
         b1 = b0 + (int64_t)64 * g.kpad;
         b2 = b0 + (int64_t)128 * g.kpad;
@@ -96,37 +101,27 @@ struct Stage<false> {
         as = (float*)lds + srow * LDA + skc;
         bs = (float*)lds + FM * LDA + srow * LDA + skc;
     }
-    __device__ __forceinline__ float4 lda(const float* p, int k) const {
-        return *reinterpret_cast<const float4*>(p + min(k, K - 4));      // K % 8 == 0, rows 16-byte aligned
-    }
     __device__ __forceinline__ void load(int kt) {
         const int k = kt * BK + skc;
-        ra0 = lda(a0, k);
-        ra1 = lda(a1, k);
+        ra0 = *reinterpret_cast<const float4*>(a0 + min(k, K - 4));     // K % 8 == 0, rows 16-byte aligned
         rb0 = *reinterpret_cast<const float4*>(b0 + kt * BK);
         rb1 = *reinterpret_cast<const float4*>(b1 + kt * BK);
         rb2 = *reinterpret_cast<const float4*>(b2 + kt * BK);
         rb3 = *reinterpret_cast<const float4*>(b3 + kt * BK);
     }
-    __device__ __forceinline__ float4 tail(float4 a, int k) const {
-        a.x = k < K ? a.x : 0.f;
-        a.y = k + 1 < K ? a.y : 0.f;
-        a.z = k + 2 < K ? a.z : 0.f;
-        a.w = k + 3 < K ? a.w : 0.f;
-        return a;
-    }
     __device__ __forceinline__ void store(int kt) {
         const int k = kt * BK + skc;
-        *reinterpret_cast<float4*>(as) = tail(ra0, k);
-        *reinterpret_cast<float4*>(as + 64 * LDA) = tail(ra1, k);
+        float4 a = ra0;
+        if (k >= K) a = make_float4(0.f, 0.f, 0.f, 0.f);               // whole chunk in or out (K % 4 == 0)
+        *reinterpret_cast<float4*>(as) = a;
         *reinterpret_cast<float4*>(bs) = rb0;
         *reinterpret_cast<float4*>(bs + 64 * LDA) = rb1;
         *reinterpret_cast<float4*>(bs + 128 * LDA) = rb2;
         *reinterpret_cast<float4*>(bs + 192 * LDA) = rb3;
     }
-    // 64 MFMAs (32x32x2 f32) on the staged tile: within an 8-wide K chunk lanes 0-31 own k 0..3 and lanes
+    // 32 MFMAs (32x32x2 f32) on the staged tile: within an 8-wide K chunk lanes 0-31 own k 0..3 and lanes
     // 32-63 own k 4..7 of both operands (a reordering of the K sum).
-    __device__ __forceinline__ void mma(const char* lds, int wr, int wc, int lane, f32x16 (&acc)[2][2]) const {
+    __device__ __forceinline__ void mma(const char* lds, int wc, int lane, f32x16 (&acc)[2][2]) const {
         const float* As = (const float*)lds;
         const float* Bs = As + FM * LDA;
         const int frow = lane & 31, fk = (lane >> 5) * 4;
@@ -135,7 +130,7 @@ struct Stage<false> {
             float4 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const float4*>(&As[(wr * 64 + i * 32 + frow) * LDA + kc * 8 + fk]);
+                a[i] = *reinterpret_cast<const float4*>(&As[(i * 32 + frow) * LDA + kc * 8 + fk]);
                 b[i] = *reinterpret_cast<const float4*>(&Bs[(wc * 64 + i * 32 + frow) * LDA + kc * 8 + fk]);
             }
 #pragma unroll
@@ -154,20 +149,20 @@ struct Stage<false> {
 template <>
 struct Stage<true> {
     static constexpr int kBK = BK16;
-    // 16-byte (8 x bf16) chunks: A 128 rows x 8 chunks = 1024 -> 2 per thread, B 256 x 8 = 2048 -> 4 per thread
-    const float *a0, *a1;
+    // 16-byte (8 x bf16) chunks: A 64 rows x 4 = 256 -> 1 per thread (two float4 loads, converted on the
+    // way into LDS), B 256 rows x 4 = 1024 -> 4 per thread
+    const float* a0;
     const __bf16 *b0, *b1, *b2, *b3;
-    float4 ra0l, ra0h, ra1l, ra1h;
+    float4 ra0l, ra0h;
     bf16x8 rb0, rb1, rb2, rb3;
     __bf16 *as, *bs;
     int skc, K;
 
     __device__ __forceinline__ void init(const FusedArgs& g, char* lds, int64_t m0, int tn, int tid) {
-        const int srow = tid >> 3;
-        skc = (tid & 7) * 8;
+        const int srow = tid >> 2;
+        skc = (tid & 3) * 8;
         K = g.K;
         a0 = g.h + min(m0 + srow, g.M - 1) * g.ldh;
-        a1 = g.h + min(m0 + srow + 64, g.M - 1) * g.ldh;
         b0 = (const __bf16*)g.w + (int64_t)(tn * FN + srow) * g.kpad + skc;
         b1 = b0 + (int64_t)64 * g.kpad;
         b2 = b0 + (int64_t)128 * g.kpad;
@@ -175,37 +170,28 @@ struct Stage<true> {
         as = (__bf16*)lds + srow * LDA16 + skc;
         bs = (__bf16*)lds + FM * LDA16 + srow * LDA16 + skc;
     }
-    __device__ __forceinline__ void lda(const float* p, int k, float4& lo, float4& hi) const {
-        const int kk = min(k, K - 8);
-        lo = *reinterpret_cast<const float4*>(p + kk);
-        hi = *reinterpret_cast<const float4*>(p + kk + 4);
-    }
     __device__ __forceinline__ void load(int kt) {
-        const int k = kt * BK16 + skc;
-        lda(a0, k, ra0l, ra0h);
-        lda(a1, k, ra1l, ra1h);
+        const int kk = min(kt * BK16 + skc, K - 8);                     // K % 8 == 0
+        ra0l = *reinterpret_cast<const float4*>(a0 + kk);
+        ra0h = *reinterpret_cast<const float4*>(a0 + kk + 4);
         rb0 = *reinterpret_cast<const bf16x8*>(b0 + kt * BK16);
         rb1 = *reinterpret_cast<const bf16x8*>(b1 + kt * BK16);
         rb2 = *reinterpret_cast<const bf16x8*>(b2 + kt * BK16);
         rb3 = *reinterpret_cast<const bf16x8*>(b3 + kt * BK16);
     }
-    __device__ __forceinline__ bf16x8 cvt(float4 lo, float4 hi, int k) const {
-        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    __device__ __forceinline__ void store(int kt) {
+        const bool live = kt * BK16 + skc < K;                          // whole chunk in or out (K % 8 == 0)
+        const float v[8] = {ra0l.x, ra0l.y, ra0l.z, ra0l.w, ra0h.x, ra0h.y, ra0h.z, ra0h.w};
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(k + j < K ? v[j] : 0.f);
-        return o;
-    }
-    __device__ __forceinline__ void store(int kt) {
-        const int k = kt * BK16 + skc;
-        *reinterpret_cast<bf16x8*>(as) = cvt(ra0l, ra0h, k);
-        *reinterpret_cast<bf16x8*>(as + 64 * LDA16) = cvt(ra1l, ra1h, k);
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(live ? v[j] : 0.f);
+        *reinterpret_cast<bf16x8*>(as) = o;
         *reinterpret_cast<bf16x8*>(bs) = rb0;
         *reinterpret_cast<bf16x8*>(bs + 64 * LDA16) = rb1;
         *reinterpret_cast<bf16x8*>(bs + 128 * LDA16) = rb2;
         *reinterpret_cast<bf16x8*>(bs + 192 * LDA16) = rb3;
     }
-    __device__ __forceinline__ void mma(const char* lds, int wr, int wc, int lane, f32x16 (&acc)[2][2]) const {
+    __device__ __forceinline__ void mma(const char* lds, int wc, int lane, f32x16 (&acc)[2][2]) const {
         const __bf16* As = (const __bf16*)lds;
         const __bf16* Bs = As + FM * LDA16;
         const int frow = lane & 31, fk = (lane >> 5) * 8;
@@ -214,7 +200,7 @@ struct Stage<true> {
             bf16x8 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const bf16x8*>(&As[(wr * 64 + i * 32 + frow) * LDA16 + ks * 16 + fk]);
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[(i * 32 + frow) * LDA16 + ks * 16 + fk]);
                 b[i] = *reinterpret_cast<const bf16x8*>(&Bs[(wc * 64 + i * 32 + frow) * LDA16 + ks * 16 + fk]);
             }
 #pragma unroll
@@ -226,22 +212,39 @@ struct Stage<true> {
     }
 };
 
+// One 32-row block of a wave's accumulators (its two column tiles) into the column-major LDS tile:
+// lane holds column (lane & 31) and rows 8q + 4*(lane >> 5) + 0..3, q = 0..3, of each MFMA tile.
+__device__ __forceinline__ void drop_block(float* tile, int ncol, int wc, int lane, const f32x16& a0, const f32x16& a1) {
+    const int col = wc * 64 + (lane & 31);
+    float* tp = tile + col * LDT + 4 * (lane >> 5);
+    if (col < ncol) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(tp + 8 * q) = make_float4(a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]);
+    }
+    if (col + 32 < ncol) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(tp + 32 * LDT + 8 * q) = make_float4(a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]);
+    }
+}
+
 template <bool BF16, int KT, bool INV>
 __global__ __launch_bounds__(FT, 4) void made_rqs_kernel(const FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    // [0, FN*LDT*4): operand staging during the K loop, then the epilogue parameter tile
+    const int fpt = g.fpt, P = g.c.P;
+    const int ncol = fpt * P;                        // live parameter columns of a tile (<= 256)
+    // [0, ncol*LDT*4): operand staging during the K loop (20 KB), then the epilogue parameter tile
     float* tile = (float*)lds;
-    float* xs = tile + FN * LDT;                     // [128][fpt] inputs, overwritten by outputs
-    float* ldp = xs + FM * g.fpt;                    // [8 waves][128] logdet sums of the features a wave evaluated
+    float* xs = tile + max(ncol * LDT, (FM + FN) * LDA);    // [64][fpt] inputs, overwritten by outputs
+    float* ldp = xs + FM * fpt;                      // [4 waves][64] logdet sums of the features a wave evaluated
 
     int64_t tm;
     int tn;
     tile_of_block(g, tm, tn);
     const int64_t m0 = tm * FM;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int fpt = g.fpt, P = g.c.P;
+    const int lane = tid & 63, wc = tid >> 6;
     const int f0 = tn * fpt;
     const int fv = min(fpt, g.feat_limit - f0);      // features of this tile to evaluate (>= 1 by construction)
 
@@ -253,8 +256,10 @@ __global__ __launch_bounds__(FT, 4) void made_rqs_kernel(const FusedArgs g) {
         xs[i] = v;
     }
 
-    const int kq = Stage<BF16>::kBK / 32;
-    const int kt_begin = g.ktab[2 * tn] / kq, kt_end = (g.ktab[2 * tn + 1] + kq - 1) / kq;
+    constexpr int kBK = Stage<BF16>::kBK;
+    constexpr int kq = kBK / 16;                     // ktab counts 16-wide K steps
+    const int kt_begin = g.ktab[2 * tn] / kq;
+    const int kt_end = min((g.ktab[2 * tn + 1] + kq - 1) / kq, (g.K + kBK - 1) / kBK);
 
     // accumulators start at the bias of their column (a lane's 16 values of one MFMA tile share a column)
     f32x16 acc[2][2];
@@ -285,49 +290,44 @@ __global__ __launch_bounds__(FT, 4) void made_rqs_kernel(const FusedArgs g) {
         STAMP(tS)
         __syncthreads();
         STAMP(tB)
+#ifndef NF_KO_LOAD
         st.load(min(kt + 1, kt_end - 1));            // prefetch under the MFMAs (last one is a re-read)
+#endif
         __builtin_amdgcn_sched_barrier(0);
         STAMP(tL)
-        st.mma(lds, wr, wc, lane, acc);
+        st.mma(lds, wc, lane, acc);
         STAMP(tM)
     }
 
-    // ---- epilogue: two halves of 64 rows through the LDS tile ---------------------------------------
-#ifdef NF_EPI_PRIO
-    __builtin_amdgcn_s_setprio(NF_EPI_PRIO);
-#endif
+    // ---- epilogue: the two 32-sample row blocks of the MFMA tiles, one after the other ---------------
+    const int hrow = lane & 31, hsel = lane >> 5;    // eval: lane = sample row of the pass, two features per wave
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-        __syncthreads();                             // staging / previous half fully consumed
+        __syncthreads();                             // staging / previous pass fully consumed
         STAMP(e0)
-        if (wr == half) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float* tp = tile + (wc * 64 + j * 32 + (lane & 31)) * LDT + 4 * (lane >> 5);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)      // rows i*32 + 8q + 4*(lane>>5) + 0..3
-                        *reinterpret_cast<float4*>(tp + i * 32 + 8 * q) =
-                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-            }
-        }
+        if (half == 0) drop_block(tile, ncol, wc, lane, acc[0][0], acc[0][1]);
+        else drop_block(tile, ncol, wc, lane, acc[1][0], acc[1][1]);
         __syncthreads();
         STAMP(e1)
-        float lsum = 0.f;                            // lane = sample row, wave-uniform feature
-        for (int e = tid; e < 64 * fv; e += FT) {
-            const int f = e >> 6;
-            const int r = half * 64 + lane;
+        float lsum = 0.f;
+        const int r = half * HR + hrow;
+        // pass `half` starts its feature pairs at wave 2*half, so the waves that take a second round differ
+        for (int e = ((wc + 2 * half) & 3) * 2 + hsel; e < fv; e += 2 * (FT / 64)) {
             float yv, ld;
             int bin;
-            rqs_eval<KT, INV, LDT>(tile + f * P * LDT + lane, xs[r * fpt + f], g.c, yv, ld, bin);
-            xs[r * fpt + f] = yv;
+#ifdef NF_KO_EPI
+            yv = tile[e * P * LDT + hrow]; ld = yv; bin = 0;
+#else
+            rqs_eval<KT, INV, LDT, true>(tile + e * P * LDT + hrow, xs[r * fpt + e], g.c, yv, ld, bin);
+#endif
+            xs[r * fpt + e] = yv;
             lsum += ld;
 #ifndef NF_STAMP
-            if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + f] = bin;
+            if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + e] = bin;
 #endif
         }
-        ldp[wave * FM + half * 64 + lane] = lsum;
+        lsum += __shfl_xor(lsum, 32, 64);
+        if (hsel == 0) ldp[wc * FM + r] = lsum;
         STAMP(e2)
     }
     __syncthreads();
@@ -345,8 +345,9 @@ __global__ __launch_bounds__(FT, 4) void made_rqs_kernel(const FusedArgs g) {
 #ifdef NF_STAMP
     STAMP(tE)
     if (g.bins && lane == 0) {
-        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * 8 + wave) * 16;
-        dbg[0] = tA; dbg[1] = tS; dbg[2] = tB; dbg[3] = tL; dbg[4] = tM; dbg[5] = tE; dbg[6] = tstart; dbg[7] = kt_end - kt_begin; dbg[8] = e0; dbg[9] = e1; dbg[10] = e2; dbg[11] = e3;
+        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * (FT / 64) + wc) * 16;
+        dbg[0] = tA; dbg[1] = tS; dbg[2] = tB; dbg[3] = tL; dbg[4] = tM; dbg[5] = tE; dbg[6] = tstart;
+        dbg[7] = kt_end - kt_begin; dbg[8] = e0; dbg[9] = e1; dbg[10] = e2; dbg[11] = e3;
     }
 #endif
 }
@@ -361,23 +362,28 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ p
 }
 
 // dst row pr of the packed matrix = src row tn*src_rows + j for j < src_rows (and in range), else zero
+// Rows of the width / height logits (parameter index < 2K within a feature) are folded with log2(e): the
+// kernel's softmax then runs on the hardware exp2 directly, softmax(u) = exp2(u' - max u') / sum.
 template <typename T>
 __global__ void pack_fused_kernel(const float* __restrict__ W, const float* __restrict__ mask,
                                   const float* __restrict__ bias, int out, int in, int src_rows, int kpad,
-                                  int64_t total, T* __restrict__ packed, float* __restrict__ bias_packed) {
+                                  int64_t total, int P, int n_logits, T* __restrict__ packed,
+                                  float* __restrict__ bias_packed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pr = i / kpad;
         const int k = (int)(i - pr * kpad);
         const int tn = (int)(pr / FN), j = (int)(pr % FN);
         const int64_t n = (int64_t)tn * src_rows + j;
         const bool live = j < src_rows && n < out;
+        const float fold = (j % P) < n_logits ? 1.44269504088896341f : 1.0f;
         float v = 0.0f;
         if (live && k < in) {
             v = W[n * in + k];
             if (mask) v *= mask[n * in + k];
+            v *= fold;
         }
         packed[i] = (T)v;
-        if (k == 0) bias_packed[pr] = (live && bias) ? bias[n] : 0.0f;
+        if (k == 0) bias_packed[pr] = (live && bias) ? bias[n] * fold : 0.0f;
     }
 }
 
@@ -404,17 +410,21 @@ __global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         if (hi < 0) { ktab[2 * tn] = 0; ktab[2 * tn + 1] = 0; }
-        else { ktab[2 * tn] = lo / 32; ktab[2 * tn + 1] = hi / 32 + 1; }
+        else { ktab[2 * tn] = lo / 16; ktab[2 * tn + 1] = hi / 16 + 1; }
     }
 }
 
-inline int kpad_of(int in) { return (in + BK16 - 1) / BK16 * BK16; }
+inline int kpad_of(int in) { return (in + KPAD - 1) / KPAD * KPAD; }
 inline int fpt_of(int P) { return FN / P; }
 inline bool fused_supported(int K, int tails) {   // (and the hidden width must be a multiple of 8)
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
     return K >= 4 && K <= 32 && P <= FN;
 }
-inline size_t lds_bytes(int fpt) { return sizeof(float) * ((size_t)FN * LDT + (size_t)FM * fpt + (size_t)FM * (FT / 64)); }
+inline size_t lds_bytes(int fpt, int P) {
+    const size_t staging = sizeof(float) * (size_t)(FM + FN) * LDA;        // == the bf16 staging size
+    const size_t tile = sizeof(float) * (size_t)fpt * P * LDT;
+    return (tile > staging ? tile : staging) + sizeof(float) * ((size_t)FM * fpt + (size_t)FM * (FT / 64));
+}
 
 template <bool BF16, int KT, bool INV>
 int launch_one(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
@@ -473,10 +483,10 @@ extern "C" int nf_made_rqs_pack(const float* W, const float* mask, const float* 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == NF_DTYPE_F32)
         hipLaunchKernelGGL(pack_fused_kernel<float>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
-                           total, (float*)packed, bias_packed);
+                           total, P, 2 * K, (float*)packed, bias_packed);
     else
         hipLaunchKernelGGL(pack_fused_kernel<__bf16>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
-                           total, (__bf16*)packed, bias_packed);
+                           total, P, 2 * K, (__bf16*)packed, bias_packed);
     if (ktab) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, fpt * P, ktab);
     return nf_launch_status();
 }
@@ -512,7 +522,7 @@ extern "C" int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const
     g.m_tiles = (B + FM - 1) / FM;
     const int64_t grid = g.m_tiles * g.n_tiles;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    const size_t lds = lds_bytes(g.fpt);
+    const size_t lds = lds_bytes(g.fpt, g.c.P);
     if (lds > 160 * 1024) return NF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     int rc = NF_OK;

@@ -97,7 +97,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Evaluates one element.  p points at its P parameters in LDS, STRIDE floats apart (1 = contiguous;
 // the fused kernel keeps its parameter tile feature-major, one row of samples per parameter).
-template <int KT, bool INV, int STRIDE = 1>
+// BASE2: the width / height logits arrive already multiplied by log2(e) (folded into the weights that
+// produced them), so the softmax exponentials are bare exp2 instructions.
+template <int KT, bool INV, int STRIDE = 1, bool BASE2 = false>
 __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, const RqsConst& a,
                                          float& y, float& ld, int& bin) {
     const int K = KT > 0 ? KT : a.K;
@@ -133,8 +135,8 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
         float w, h;
         if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
         else { w = raw(uw, k); h = raw(uh, k); }
-        w = nf_exp(w - mw);
-        h = nf_exp(h - mh);
+        w = BASE2 ? __builtin_amdgcn_exp2f(w - mw) : nf_exp(w - mw);
+        h = BASE2 ? __builtin_amdgcn_exp2f(h - mh) : nf_exp(h - mh);
         if constexpr (KT > 0) { ew[k] = w; eh[k] = h; }
         sw += w;
         sh += h;
@@ -151,6 +153,7 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
     for (int k = 0; k < K; ++k) {
         float w, h;
         if constexpr (KT > 0) { w = ew[k]; h = eh[k]; }
+        else if (BASE2) { w = __builtin_amdgcn_exp2f(raw(uw, k) - mw); h = __builtin_amdgcn_exp2f(raw(uh, k) - mh); }
         else { w = nf_exp(raw(uw, k) - mw); h = nf_exp(raw(uh, k) - mh); }
         w = a.min_w + a.scale_w * (w * rw);
         h = a.min_h + a.scale_h * (h * rh);
