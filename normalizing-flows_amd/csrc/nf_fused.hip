@@ -28,7 +28,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int FM = 64, FN = 256;        // block tile: 64 samples x 256 parameter columns
 constexpr int FT = 256;                 // threads: 4 waves side by side, 64 x 64 outputs each (2x2 MFMA tiles)
-constexpr int BK = 16, LDA = BK + 4;    // fp32 staging: K tile and padded LDS row (floats)
+#ifndef NF_FBK
+#define NF_FBK 16
+#endif
+#ifndef NF_FOCC
+#define NF_FOCC 4
+#endif
+constexpr int BK = NF_FBK, LDA = BK + 4; // fp32 staging: K tile and padded LDS row (floats)
 constexpr int BK16 = 32, LDA16 = BK16 + 8;   // bf16 staging (elements); both rows are 80 bytes: conflict-free b128
 constexpr int KPAD = 64;                // packed weight rows are padded to this many K elements
 constexpr int HR = 32;                  // epilogue: samples per pass through the LDS parameter tile
@@ -83,44 +89,43 @@ struct Stage;
 template <>
 struct Stage<false> {
     static constexpr int kBK = BK;
-    // 16-byte chunks: A 64 rows x 4 = 256 -> 1 per thread, B 256 rows x 4 = 1024 -> 4 per thread
-    const float *a0, *b0, *b1, *b2, *b3;
-    float4 ra0, rb0, rb1, rb2, rb3;
+    // 16-byte chunks: CPR per row, the 256 threads cover RPP rows per pass: NA passes for A, NB for B
+    static constexpr int CPR = BK / 4, RPP = FT / CPR, NA = FM / RPP, NB = FN / RPP;
+    const float* a[NA];
+    const float* b0;
+    int64_t bstep;
+    float4 ra[NA], rb[NB];
     float *as, *bs;
     int skc, K;
 
     __device__ __forceinline__ void init(const FusedArgs& g, char* lds, int64_t m0, int tn, int tid) {
-        const int srow = tid >> 2;
-        skc = (tid & 3) * 4;
+        const int srow = tid / CPR;
+        skc = (tid % CPR) * 4;
         K = g.K;
-        a0 = g.h + min(m0 + srow, g.M - 1) * g.ldh;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[i] = g.h + min(m0 + srow + i * RPP, g.M - 1) * g.ldh;
         b0 = (const float*)g.w + (int64_t)(tn * FN + srow) * g.kpad + skc;
-        b1 = b0 + (int64_t)64 * g.kpad;
-        b2 = b0 + (int64_t)128 * g.kpad;
-        b3 = b0 + (int64_t)192 * g.kpad;
+        bstep = (int64_t)RPP * g.kpad;
         as = (float*)lds + srow * LDA + skc;
         bs = (float*)lds + FM * LDA + srow * LDA + skc;
     }
     __device__ __forceinline__ void load(int kt) {
         const int k = kt * BK + skc;
-        ra0 = *reinterpret_cast<const float4*>(a0 + min(k, K - 4));     // K % 8 == 0, rows 16-byte aligned
-        rb0 = *reinterpret_cast<const float4*>(b0 + kt * BK);
-        rb1 = *reinterpret_cast<const float4*>(b1 + kt * BK);
-        rb2 = *reinterpret_cast<const float4*>(b2 + kt * BK);
-        rb3 = *reinterpret_cast<const float4*>(b3 + kt * BK);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a[i] + min(k, K - 4));   // K % 8 == 0
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4*>(b0 + i * bstep + kt * BK);
     }
     __device__ __forceinline__ void store(int kt) {
-        const int k = kt * BK + skc;
-        float4 a = ra0;
-        if (k >= K) a = make_float4(0.f, 0.f, 0.f, 0.f);               // whole chunk in or out (K % 4 == 0)
-        *reinterpret_cast<float4*>(as) = a;
-        *reinterpret_cast<float4*>(bs) = rb0;
-        *reinterpret_cast<float4*>(bs + 64 * LDA) = rb1;
-        *reinterpret_cast<float4*>(bs + 128 * LDA) = rb2;
-        *reinterpret_cast<float4*>(bs + 192 * LDA) = rb3;
+        const bool live = kt * BK + skc < K;                            // whole chunk in or out (K % 4 == 0)
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            *reinterpret_cast<float4*>(as + i * RPP * LDA) = live ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(bs + i * RPP * LDA) = rb[i];
     }
-    // 32 MFMAs (32x32x2 f32) on the staged tile: within an 8-wide K chunk lanes 0-31 own k 0..3 and lanes
-    // 32-63 own k 4..7 of both operands (a reordering of the K sum).
+    // BK/2 x 4 MFMAs (32x32x2 f32) on the staged tile: within an 8-wide K chunk lanes 0-31 own k 0..3 and
+    // lanes 32-63 own k 4..7 of both operands (a reordering of the K sum).
     __device__ __forceinline__ void mma(const char* lds, int wc, int lane, f32x16 (&acc)[2][2]) const {
         const float* As = (const float*)lds;
         const float* Bs = As + FM * LDA;
@@ -230,7 +235,7 @@ __device__ __forceinline__ void drop_block(float* tile, int ncol, int wc, int la
 }
 
 template <bool BF16, int KT, bool INV>
-__global__ __launch_bounds__(FT, 4) void made_rqs_kernel(const FusedArgs g) {
+__global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int fpt = g.fpt, P = g.c.P;
     const int ncol = fpt * P;                        // live parameter columns of a tile (<= 256)
@@ -421,7 +426,7 @@ inline bool fused_supported(int K, int tails) {   // (and the hidden width must 
     return K >= 4 && K <= 32 && P <= FN;
 }
 inline size_t lds_bytes(int fpt, int P) {
-    const size_t staging = sizeof(float) * (size_t)(FM + FN) * LDA;        // == the bf16 staging size
+    const size_t staging = sizeof(float) * (size_t)(FM + FN) * LDA;        // >= the bf16 staging size
     const size_t tile = sizeof(float) * (size_t)fpt * P * LDT;
     return (tile > staging ? tile : staging) + sizeof(float) * ((size_t)FM * fpt + (size_t)FM * (FT / 64));
 }
