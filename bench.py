@@ -33,9 +33,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE doubled as the
-# microarch guide prescribes for gfx950, + WRITE_SIZE), collected separately: profiles/r01_f_f32_fused_pmc.txt.
+# microarch guide prescribes for gfx950, + WRITE_SIZE), collected separately: profiles/r01_h_f32_fused64_pmc.txt.
 # Keyed by (dtype, fused kernel?, rows per launch); other shapes report null.
-TRAFFIC_BYTES_PER_LAUNCH = {('f32', True, 131072): 7.07e9}
+TRAFFIC_BYTES_PER_LAUNCH = {('f32', True, 131072): 5.72e9}
 
 
 def build_flow(nf):
