@@ -118,6 +118,11 @@ size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, int tails);
  * its K-tile table (2*tiles int32) and its bias (tiles*256 floats). */
 int nf_made_rqs_pack(const float* W, const float* mask, const float* bias, int features, int in, int K,
                      int tails, int dtype, void* packed, int32_t* ktab, float* bias_packed, void* stream);
+/* Same with the width / height logits divided by `logit_div` first (the coupling layers' in-place
+ * `/= sqrt(hidden_features)`, transforms.py:221-229); the division is folded into the packed rows. */
+int nf_made_rqs_pack_scaled(const float* W, const float* mask, const float* bias, int features, int in, int K,
+                            int tails, int dtype, double logit_div, void* packed, int32_t* ktab, float* bias_packed,
+                            void* stream);
 /* y, logabsdet (and optionally bin_idx) of the spline whose parameters are h @ Wm^T + bias; semantics of
  * x, y, logabsdet, accumulate, bin_idx, tails, tail_bound, min_* and inverse as in nf_rqs_fwd
  * (no feat_index, pre_div = 1: the autoregressive path). */
@@ -138,6 +143,18 @@ int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const void* pack
                           int tails, double tail_bound, double min_bin_width, double min_bin_height,
                           double min_derivative, int inverse, int dtype, int tile_begin, int tile_count,
                           int feat_limit, int reduce, void* stream);
+
+/* Coupling layer (replaces the conditioner's final Linear, resnet.py:99, + transforms.py:156-168, :212-247
+ * `_coupling_transform` / `_piecewise_cdf` + rational_quadratic.py:13-149): h [B, in] is the ResidualNet's last
+ * hidden state, packed_w from nf_made_rqs_pack_scaled(mask = NULL); feature f of the spline reads
+ * x[b, feat_index[f]] and writes y[b, feat_index[f]] (rows `row_width` columns wide; the identity columns of
+ * y are the caller's).  The [B, features*P] parameter tensor is never written. */
+int nf_coupling_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                        const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                        int64_t y_row_stride, const int32_t* feat_index, int row_width, float* logabsdet,
+                        int accumulate, int32_t* bin_idx, float* workspace, size_t workspace_bytes, int64_t B,
+                        int in, int features, int K, int tails, double tail_bound, double min_bin_width,
+                        double min_bin_height, double min_derivative, int inverse, int dtype, void* stream);
 
 /* ---- affine transform (replaces transforms.py:328-347 coupling, :540-566 autoregressive) -------- */
 

@@ -55,6 +55,14 @@ _SIGNATURES = {
     'nf_made_rqs_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
     'nf_made_rqs_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                     _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'nf_made_rqs_pack_scaled': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_int, _c.c_int, _c.c_double, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                           _c.c_void_p]),
+    'nf_coupling_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                       _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                       _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int,
+                                       _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
+                                       _c.c_double, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_made_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -243,7 +251,7 @@ class PackedFusedFinal:
     """Device buffers of nf_made_rqs_pack: the final MADE layer regrouped to whole features per tile."""
     __slots__ = ('features', 'inp', 'K', 'tails', 'dtype', 'packed', 'ktab', 'bias', 'tiles')
 
-    def __init__(self, weight, mask, bias, features, num_bins, tails, dtype=NF_DTYPE_F32):
+    def __init__(self, weight, mask, bias, features, num_bins, tails, dtype=NF_DTYPE_F32, logit_div=1.0):
         lib = load()
         w = _dev(weight.detach().contiguous(), 'weight')
         m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
@@ -258,9 +266,9 @@ class PackedFusedFinal:
         self.ktab = torch.empty(2 * self.tiles, dtype=torch.int32, device=w.device)
         self.bias = torch.empty(256 * self.tiles, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            _check(lib.nf_made_rqs_pack(w.data_ptr(), _ptr(m), _ptr(b), self.features, self.inp, self.K, t, dtype,
-                                        self.packed.data_ptr(), self.ktab.data_ptr(), self.bias.data_ptr(),
-                                        _stream()), 'nf_made_rqs_pack')
+            _check(lib.nf_made_rqs_pack_scaled(w.data_ptr(), _ptr(m), _ptr(b), self.features, self.inp, self.K, t,
+                                               dtype, float(logit_div), self.packed.data_ptr(), self.ktab.data_ptr(),
+                                               self.bias.data_ptr(), _stream()), 'nf_made_rqs_pack')
 
 
 def made_rqs_supported(num_bins, tails, hidden):
@@ -270,17 +278,25 @@ def made_rqs_supported(num_bins, tails, hidden):
 
 def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accumulate=False, min_bin_width=1e-3,
              min_bin_height=1e-3, min_derivative=1e-3, want_bins=False, tiles=None, feat_limit=None, reduce=True,
-             workspace=None):
+             workspace=None, feat_index=None):
     """Fused final MADE layer + spline: h [B, hidden], x [B, features] -> (y, logabsdet[B], bins or None).
-    `tiles=(begin, count)`, `feat_limit`, `reduce`, `workspace`: one pass of the incremental inverse."""
+    `tiles=(begin, count)`, `feat_limit`, `reduce`, `workspace`: one pass of the incremental inverse.
+    `feat_index` (int32 [features]): coupling layers - feature f lives in column feat_index[f] of x and y,
+    whose other columns are left alone (nf_coupling_rqs_fwd)."""
     lib = load()
     _dev(h, 'hidden')
     _dev(x, 'inputs')
     B = x.shape[0]
     hp, hs = _rows(h, 'hidden')
     xp, xs = _rows(x, 'inputs')
-    if h.shape[0] != B or h.shape[1] != pf.inp or x.shape[1] != pf.features:
+    if h.shape[0] != B or h.shape[1] != pf.inp or (feat_index is None and x.shape[1] != pf.features):
         raise ValueError('Expected hidden [B,%d] and inputs [B,%d]' % (pf.inp, pf.features))
+    if feat_index is not None:
+        _dev(feat_index, 'feat_index', torch.int32)
+        if feat_index.dtype != torch.int32 or feat_index.numel() != pf.features or out is None \
+                or out.shape != x.shape or tiles is not None or feat_limit is not None:
+            raise ValueError('coupling launch: int32 feat_index [%d], caller-provided outputs, no tile window'
+                             % pf.features)
     if out is None:
         out = torch.empty_like(x)
     yp, ys = _rows(out, 'outputs')
@@ -294,6 +310,13 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
     fl = pf.features if feat_limit is None else feat_limit
 
     def launch():
+        if feat_index is not None:
+            return lib.nf_coupling_rqs_fwd(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs,
+                                           yp, ys, feat_index.data_ptr(), x.shape[1], logabsdet.data_ptr(),
+                                           int(accumulate), _ptr(bins), ws.data_ptr(), ws.numel() * 4, B, pf.inp,
+                                           pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
+                                           float(min_bin_height), float(min_derivative), int(inverse), pf.dtype,
+                                           _stream())
         return lib.nf_made_rqs_fwd_tiles(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs,
                                          yp, ys, logabsdet.data_ptr(), int(accumulate), _ptr(bins), ws.data_ptr(),
                                          ws.numel() * 4, B, pf.inp, pf.features, pf.K, pf.tails, float(tail_bound),

@@ -55,6 +55,7 @@ struct FusedArgs {
     int64_t ldy;
     float* partial;          // [n_tiles][M]
     int32_t* bins;           // nullable [M, D]
+    const int32_t* feat_index;   // nullable [D]: column of x / y that holds feature f (coupling layers)
     int64_t M;
     int K, D;
     int fpt;                 // features per tile
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
     for (int i = tid; i < FM * fpt; i += FT) {
         const int r = i / fpt, f = i - r * fpt;
         float v = 0.f;
-        if (m0 + r < g.M && f < fv) v = g.x[(m0 + r) * g.ldx + f0 + f];
+        if (m0 + r < g.M && f < fv) v = g.x[(m0 + r) * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)];
         xs[i] = v;
     }
 
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
     STAMP(e3)
     for (int i = tid; i < FM * fpt; i += FT) {
         const int r = i / fpt, f = i - r * fpt;
-        if (m0 + r < g.M && f < fv) g.y[(m0 + r) * g.ldy + f0 + f] = xs[i];
+        if (m0 + r < g.M && f < fv) g.y[(m0 + r) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = xs[i];
     }
 #ifdef NF_STAMP
     STAMP(tE)
@@ -367,12 +368,13 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ p
 }
 
 // dst row pr of the packed matrix = src row tn*src_rows + j for j < src_rows (and in range), else zero
-// Rows of the width / height logits (parameter index < 2K within a feature) are folded with log2(e): the
-// kernel's softmax then runs on the hardware exp2 directly, softmax(u) = exp2(u' - max u') / sum.
+// Rows of the width / height logits (parameter index < 2K within a feature) are folded with log2(e) / logit_div:
+// the kernel's softmax then runs on the hardware exp2 directly, softmax(u / div) = exp2(u' - max u') / sum
+// (logit_div is the coupling layers' sqrt(hidden_features), transforms.py:221-229; 1 on the autoregressive path).
 template <typename T>
 __global__ void pack_fused_kernel(const float* __restrict__ W, const float* __restrict__ mask,
                                   const float* __restrict__ bias, int out, int in, int src_rows, int kpad,
-                                  int64_t total, int P, int n_logits, T* __restrict__ packed,
+                                  int64_t total, int P, int n_logits, float logit_fold, T* __restrict__ packed,
                                   float* __restrict__ bias_packed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pr = i / kpad;
@@ -380,7 +382,7 @@ __global__ void pack_fused_kernel(const float* __restrict__ W, const float* __re
         const int tn = (int)(pr / FN), j = (int)(pr % FN);
         const int64_t n = (int64_t)tn * src_rows + j;
         const bool live = j < src_rows && n < out;
-        const float fold = (j % P) < n_logits ? 1.44269504088896341f : 1.0f;
+        const float fold = (j % P) < n_logits ? logit_fold : 1.0f;
         float v = 0.0f;
         if (live && k < in) {
             v = W[n * in + k];
@@ -476,10 +478,12 @@ extern "C" size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, in
     return nt == 0 || B <= 0 ? 0 : sizeof(float) * (size_t)nt * (size_t)B;
 }
 
-extern "C" int nf_made_rqs_pack(const float* W, const float* mask, const float* bias, int features, int in, int K,
-                                int tails, int dtype, void* packed, int32_t* ktab, float* bias_packed, void* stream) {
+extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const float* bias, int features, int in,
+                                       int K, int tails, int dtype, double logit_div, void* packed, int32_t* ktab,
+                                       float* bias_packed, void* stream) {
     if (!W || !packed || !bias_packed) return NF_ERR_NULL;     // ktab == NULL: keep the caller's table
-    if (features <= 0 || in <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
+    if (features <= 0 || in <= 0 || !fused_supported(K, tails) || !(logit_div > 0.0)) return NF_ERR_SHAPE;
+    const float logit_fold = (float)(1.4426950408889634 / logit_div);
     if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
     const int fpt = fpt_of(P), nt = (features + fpt - 1) / fpt, out = features * P, kpad = kpad_of(in);
@@ -488,27 +492,32 @@ extern "C" int nf_made_rqs_pack(const float* W, const float* mask, const float* 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == NF_DTYPE_F32)
         hipLaunchKernelGGL(pack_fused_kernel<float>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
-                           total, P, 2 * K, (float*)packed, bias_packed);
+                           total, P, 2 * K, logit_fold, (float*)packed, bias_packed);
     else
         hipLaunchKernelGGL(pack_fused_kernel<__bf16>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
-                           total, P, 2 * K, (__bf16*)packed, bias_packed);
+                           total, P, 2 * K, logit_fold, (__bf16*)packed, bias_packed);
     if (ktab) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, fpt * P, ktab);
     return nf_launch_status();
 }
 
-extern "C" int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
-                                     const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
-                                     int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
-                                     float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
-                                     int tails, double tail_bound, double min_bin_width, double min_bin_height,
-                                     double min_derivative, int inverse, int dtype, int tile_begin, int tile_count,
-                                     int feat_limit, int reduce, void* stream) {
+extern "C" int nf_made_rqs_pack(const float* W, const float* mask, const float* bias, int features, int in, int K,
+                                int tails, int dtype, void* packed, int32_t* ktab, float* bias_packed, void* stream) {
+    return nf_made_rqs_pack_scaled(W, mask, bias, features, in, K, tails, dtype, 1.0, packed, ktab, bias_packed, stream);
+}
+
+static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                          const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                          int64_t y_row_stride, const int32_t* feat_index, int row_width, float* logabsdet,
+                          int accumulate, int32_t* bin_idx, float* workspace, size_t workspace_bytes, int64_t B, int in,
+                          int features, int K, int tails, double tail_bound, double min_bin_width,
+                          double min_bin_height, double min_derivative, int inverse, int dtype, int tile_begin,
+                          int tile_count, int feat_limit, int reduce, void* stream) {
     if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
     if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
     if (B == 0) return NF_OK;
     if (!h || !packed_w || !ktab || !bias_packed || !x || !y || !logabsdet || !workspace) return NF_ERR_NULL;
-    if (h_row_stride < in || x_row_stride < features || y_row_stride < features) return NF_ERR_LAYOUT;
+    if (h_row_stride < in || x_row_stride < row_width || y_row_stride < row_width) return NF_ERR_LAYOUT;
     // the hidden state is staged with 16-byte loads only (it comes from nf_masked_linear_fwd)
     if (in % 8 != 0 || h_row_stride % 4 != 0 || ((uintptr_t)h & 15) != 0) return NF_ERR_LAYOUT;
     if (workspace_bytes < nf_made_rqs_workspace_bytes(B, features, K, tails)) return NF_ERR_SCRATCH;
@@ -516,7 +525,7 @@ extern "C" int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const
     FusedArgs g;
     g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
-    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
@@ -541,6 +550,34 @@ extern "C" int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const
     hipLaunchKernelGGL(rowsum_kernel, dim3(nf_ceil_div(B, 256)), dim3(256), 0, s, workspace, all_tiles, B, logabsdet,
                        accumulate);
     return nf_launch_status();
+}
+
+extern "C" int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                                     const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                                     int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                                     float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
+                                     int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                                     double min_derivative, int inverse, int dtype, int tile_begin, int tile_count,
+                                     int feat_limit, int reduce, void* stream) {
+    return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr,
+                          features, logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
+                          tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, tile_begin,
+                          tile_count, feat_limit, reduce, stream);
+}
+
+extern "C" int nf_coupling_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                                   const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                                   int64_t y_row_stride, const int32_t* feat_index, int row_width, float* logabsdet,
+                                   int accumulate, int32_t* bin_idx, float* workspace, size_t workspace_bytes,
+                                   int64_t B, int in, int features, int K, int tails, double tail_bound,
+                                   double min_bin_width, double min_bin_height, double min_derivative, int inverse,
+                                   int dtype, void* stream) {
+    if (!feat_index) return NF_ERR_NULL;
+    if (row_width < features) return NF_ERR_SHAPE;
+    return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, feat_index,
+                          row_width, logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K,
+                          tails, tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
+                          nf_made_rqs_tiles(features, K, tails), features, 1, stream);
 }
 
 extern "C" int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,

@@ -72,14 +72,14 @@ class _PackedMixin:
             cached = self._pack_cache
         return cached[1]
 
-    def _packed_fused_final(self, features, num_bins, tails):
+    def _packed_fused_final(self, features, num_bins, tails, logit_div=1.0):
         """Final layer regrouped for the fused GEMM + spline kernel (nf_made_rqs_pack), cached likewise."""
         key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
-               get_matmul_dtype(), self.weight.device, features, num_bins, tails)
+               get_matmul_dtype(), self.weight.device, features, num_bins, tails, float(logit_div))
         cached = getattr(self, '_fused_cache', None)
         if cached is None or cached[0] != key:
             pf = _lib.PackedFusedFinal(self.weight, getattr(self, 'mask', None), self.bias, features, num_bins, tails,
-                                       _MATMUL_DTYPE[get_matmul_dtype()])
+                                       _MATMUL_DTYPE[get_matmul_dtype()], logit_div=logit_div)
             object.__setattr__(self, '_fused_cache', (key, pf))
             cached = self._fused_cache
         return cached[1]

@@ -60,10 +60,14 @@ class ResidualNet(nn.Module):
             for _ in range(num_blocks)])
         self.final_layer = DenseLinear(hidden_features, out_features)
 
-    def forward(self, inputs, context=None):
+    def forward_hidden(self, inputs, context=None):
+        """Everything but the final layer (which the coupling transforms fuse with their spline)."""
         if context is not None:
             inputs = torch.cat((inputs, context), dim=1)
         temps = self.initial_layer(inputs)
         for block in self.blocks:
             temps = block(temps, context=context)
-        return self.final_layer(temps)
+        return temps
+
+    def forward(self, inputs, context=None):
+        return self.final_layer(self.forward_hidden(inputs, context))

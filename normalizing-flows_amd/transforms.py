@@ -16,6 +16,7 @@ from torch.nn import functional as F
 
 from . import _lib
 from . import made as made_module
+from .resnet import ResidualNet
 
 DEFAULT_MIN_BIN_WIDTH = 1e-3
 DEFAULT_MIN_BIN_HEIGHT = 1e-3
@@ -366,14 +367,44 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         else:
             return self.num_bins * 3 + 1
 
-    def _coupling_elementwise(self, inputs, transform_params, outputs, logabsdet, inverse):
+    def _pre_div(self):
         if hasattr(self.transform_net, 'hidden_features'):
-            pre_div = np.sqrt(self.transform_net.hidden_features)
-        elif hasattr(self.transform_net, 'hidden_channels'):
-            pre_div = np.sqrt(self.transform_net.hidden_channels)
-        else:
-            warnings.warn('Inputs to the softmax are not scaled down: initialization might be bad.')
-            pre_div = 1.0
+            return np.sqrt(self.transform_net.hidden_features)
+        if hasattr(self.transform_net, 'hidden_channels'):
+            return np.sqrt(self.transform_net.hidden_channels)
+        warnings.warn('Inputs to the softmax are not scaled down: initialization might be bad.')
+        return 1.0
+
+    def _fusable(self, inputs):
+        """The conditioner's final Linear + the spline run as one launch (nf_coupling_rqs_fwd) when the
+        conditioner is this package's ResidualNet in inference mode and the spline shape fits the kernel."""
+        net = self.transform_net
+        return (isinstance(net, ResidualNet) and not net.training
+                and not (torch.is_grad_enabled() and inputs.requires_grad)
+                and self.tails in (None, 'linear')
+                and _lib.made_rqs_supported(self.num_bins, self.tails, net.hidden_features))
+
+    def _run(self, inputs, context, inverse, want_bins=False):
+        if not self._fusable(inputs):
+            return super()._run(inputs, context, inverse)
+        _check_2d(inputs, self.features)
+        if not inputs.is_contiguous():
+            inputs = inputs.contiguous()
+        net = self.transform_net
+        hidden = net.forward_hidden(inputs[:, self.identity_features].contiguous(), context)
+        pf = net.final_layer._packed_fused_final(self.num_transform_features, self.num_bins, self.tails,
+                                                 logit_div=self._pre_div())
+        outputs = inputs.clone()                       # identity columns pass through
+        _, logabsdet, bins = _lib.made_rqs(hidden, pf, inputs, self.tail_bound, inverse=inverse, out=outputs,
+                                           min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                                           min_derivative=self.min_derivative, feat_index=self._feat_index(),
+                                           want_bins=want_bins)
+        if want_bins:
+            return outputs, logabsdet, bins
+        return outputs, logabsdet
+
+    def _coupling_elementwise(self, inputs, transform_params, outputs, logabsdet, inverse):
+        pre_div = self._pre_div()
         if self.tails not in (None, 'linear'):
             raise RuntimeError('{} tails are not implemented.'.format(self.tails))
         _lib.rqs(inputs, transform_params, self.num_bins, self.tails, self.tail_bound, inverse=inverse,

@@ -399,6 +399,38 @@ def test_rq_coupling_golden(nf, tag):
     assert_close(ldi, -fx['ld64'], fx['inv_of_y_ld'])
 
 
+@pytest.mark.parametrize('tails', ['linear', None])
+@pytest.mark.parametrize('B', [1, 63, 1000])
+def test_rq_coupling_fused_equals_two_kernel_route(nf, tails, B):
+    """nf_coupling_rqs_fwd (final Linear + spline in one launch, logits / sqrt(hidden) folded into the packed
+    rows) against the conditioner GEMM + nf_rqs_fwd route on the same layer, ragged batch sizes."""
+    torch.manual_seed(3)
+    D, Hn = 10, 32
+    mask = torch.zeros(D)
+    mask[1::3] = 1
+    layer = nf.PiecewiseRationalQuadraticCouplingTransform(
+        mask, lambda i, o: nf.ResidualNet(i, o, hidden_features=Hn, num_blocks=2), num_bins=8, tails=tails,
+        tail_bound=2.5 if tails else 1.0).cuda().eval()
+    for p in layer.parameters():
+        p.data.mul_(3.0)
+    x = torch.randn(B, D, device='cuda') if tails else torch.rand(B, D, device='cuda')
+    from oracle import nf_oracle as O
+    sd32 = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}
+    with torch.no_grad():
+        for inverse in (False, True):
+            assert layer._fusable(x)
+            y, ld, bins = layer._run(x, None, inverse, want_bins=True)
+            y0, ld0 = nf.transforms.CouplingTransform._run(layer, x, None, inverse)     # GEMM + nf_rqs_fwd
+            r32 = O.rq_coupling(sd32, x.cpu(), 8, tails, 2.5 if tails else 1.0, Hn, inverse=inverse)
+            r64 = O.rq_coupling(sd64, x.cpu().double(), 8, tails, 2.5 if tails else 1.0, Hn, inverse=inverse)
+            assert torch.equal(y[:, layer.identity_features], x[:, layer.identity_features])
+            for got in ((y, ld), (y0, ld0)):
+                assert_close(got[0], r64[0], r32[0])
+                assert_close(got[1], r64[1], r32[1])
+            assert bins.shape == (B, layer.num_transform_features) and int(bins.max()) <= 7
+
+
 def test_affine_coupling_golden(nf):
     fx = load_golden('affine_coupling')
     comp = _coupling_stack(nf, fx, 'affine')
