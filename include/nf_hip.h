@@ -156,6 +156,21 @@ int nf_coupling_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed
                         int in, int features, int K, int tails, double tail_bound, double min_bin_width,
                         double min_bin_height, double min_derivative, int inverse, int dtype, void* stream);
 
+/* ---- coupling conditioner: the ResidualNet's hidden stack in one launch ------------------------------
+ *      (replaces resnet.py:96-98 `initial_layer` + `blocks` and the `inputs[:, identity_features]` gather of
+ *       transforms.py:88; BatchNorm in eval mode folded to scale/shift; no context, ReLU only) --------- */
+
+/* Length in floats of the parameter blob: Kp = n_in rounded up to 8,
+ *   W0[hidden][Kp] (zero padded) b0[hidden]
+ *   per block: s0[hidden] t0[hidden] Wa[hidden][hidden] ba[hidden] s1[hidden] t1[hidden] Wb[hidden][hidden] bb[hidden]
+ * with s/t the eval-BatchNorm scale/shift applied before each ReLU (1 / 0 without BatchNorm). */
+size_t nf_resnet_blob_floats(int n_in, int hidden, int num_blocks);
+/* h[b, :] = hidden state after the last residual block for inputs x[b, in_index[0..n_in)] (in_index NULL:
+ * the first n_in columns); rows of x are `row_width` columns wide.  hidden % 32 == 0, n_in, hidden <= 128. */
+int nf_resnet_hidden_fwd(const float* x, int64_t x_row_stride, const int32_t* in_index, int n_in, int row_width,
+                         const float* blob, int hidden, int num_blocks, float* h, int64_t h_row_stride,
+                         int64_t B, void* stream);
+
 /* ---- affine transform (replaces transforms.py:328-347 coupling, :540-566 autoregressive) -------- */
 
 /* scale = sigmoid(u + 2) + 1e-3; forward y = scale*x + shift, inverse y = (x - shift)/scale;

@@ -63,6 +63,9 @@ _SIGNATURES = {
                                        _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int,
                                        _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
                                        _c.c_double, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_resnet_blob_floats': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    'nf_resnet_hidden_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p,
+                                        _c.c_int, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
     'nf_made_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -327,6 +330,36 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
         code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * (3 * pf.K - 1), B), launch)
         _check(code, 'nf_made_rqs_fwd')
     return out, logabsdet, bins
+
+
+def resnet_hidden_supported(n_in, hidden):
+    return 0 < n_in <= 128 and 0 < hidden <= 128 and hidden % 32 == 0
+
+
+def resnet_hidden(x, in_index, blob, n_in, hidden, num_blocks):
+    """Hidden state [B, hidden] of a ResidualNet (blob layout: nf_resnet_blob_floats) on columns `in_index`
+    (int32, or None for the first n_in) of x."""
+    lib = load()
+    _dev(x, 'inputs')
+    _dev(blob, 'blob')
+    if in_index is not None:
+        _dev(in_index, 'in_index', torch.int32)
+        if in_index.numel() != n_in:
+            raise ValueError('in_index must have %d entries' % n_in)
+    if blob.numel() != lib.nf_resnet_blob_floats(n_in, hidden, num_blocks):
+        raise ValueError('parameter blob has %d floats, expected %d'
+                         % (blob.numel(), lib.nf_resnet_blob_floats(n_in, hidden, num_blocks)))
+    xp, xs = _rows(x, 'inputs')
+    B = x.shape[0]
+    h = torch.empty((B, hidden), dtype=torch.float32, device=x.device)
+
+    def launch():
+        return lib.nf_resnet_hidden_fwd(xp, xs, _ptr(in_index), n_in, x.shape[1], blob.data_ptr(), hidden, num_blocks,
+                                        h.data_ptr(), hidden, B, _stream())
+    with torch.cuda.device(x.device):
+        code = launch() if _timer is None else _timer.record(('resnet_hidden', n_in, hidden, B), launch)
+        _check(code, 'nf_resnet_hidden_fwd')
+    return h
 
 
 def masked_linear(x, pl, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False, out=None,

@@ -8,6 +8,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F, init
 
+from . import _lib
 from .made import DenseLinear, _bn_scale_shift, _check_activation
 
 
@@ -59,6 +60,51 @@ class ResidualNet(nn.Module):
                           dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
             for _ in range(num_blocks)])
         self.final_layer = DenseLinear(hidden_features, out_features)
+
+    def _hidden_blob(self):
+        """Parameters of the hidden stack in the layout of nf_resnet_blob_floats, rebuilt when any changes."""
+        tensors = [self.initial_layer.weight, self.initial_layer.bias]
+        for blk in self.blocks:
+            for j in range(2):
+                if blk.use_batch_norm:
+                    bn = blk.batch_norm_layers[j]
+                    tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+                tensors += [blk.linear_layers[j].weight, blk.linear_layers[j].bias]
+        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.initial_layer.weight.device,)
+        cached = getattr(self, '_blob_cache', None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                w0 = self.initial_layer.weight
+                kp = (w0.shape[1] + 7) // 8 * 8
+                parts = [F.pad(w0, (0, kp - w0.shape[1])).reshape(-1), self.initial_layer.bias]
+                for blk in self.blocks:
+                    for j in range(2):
+                        if blk.use_batch_norm:
+                            sc, sh = _bn_scale_shift(blk.batch_norm_layers[j])
+                        else:
+                            sc, sh = torch.ones_like(self.initial_layer.bias), torch.zeros_like(self.initial_layer.bias)
+                        parts += [sc, sh, blk.linear_layers[j].weight.reshape(-1), blk.linear_layers[j].bias]
+                blob = torch.cat([p.detach().float().reshape(-1) for p in parts]).contiguous()
+            object.__setattr__(self, '_blob_cache', (key, blob))
+            cached = self._blob_cache
+        return cached[1]
+
+    def records_grad(self, inputs):
+        """True when autograd would record this call (the inference-only fused kernels must not run then)."""
+        return torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
+
+    def hidden_stack_fusable(self, inputs, context=None):
+        """One launch for initial layer + blocks (nf_resnet_hidden_fwd): inference, no context, ReLU,
+        hidden width a multiple of 32 up to 128."""
+        return (context is None and self.context_features is None and not self.records_grad(inputs)
+                and not any(b.use_batch_norm and b.training for b in self.blocks)
+                and all(b.activation in (F.relu, torch.relu) for b in self.blocks)
+                and _lib.resnet_hidden_supported(self.initial_layer.in_features, self.hidden_features))
+
+    def forward_hidden_columns(self, inputs, columns):
+        """forward_hidden(inputs[:, columns]) without materialising the gather; `columns` int32 on the device."""
+        return _lib.resnet_hidden(inputs, columns, self._hidden_blob(), self.initial_layer.in_features,
+                                  self.hidden_features, len(self.blocks))
 
     def forward_hidden(self, inputs, context=None):
         """Everything but the final layer (which the coupling transforms fuse with their spline)."""

@@ -299,14 +299,18 @@ class CouplingTransform(nn.Module):
     def num_transform_features(self):
         return len(self.transform_features)
 
-    def _feat_index(self):
-        # int32 copy of the column index of each transformed feature, for the kernels
-        t = self.transform_features
-        key = (t.device, t._version)
-        c = getattr(self, '_feat_cache', None)
+    def _index32(self, name):
+        # int32 copy of an index buffer, for the kernels
+        t = getattr(self, name)
+        key = (t.device, t._version, t.data_ptr())
+        cache = self.__dict__.setdefault('_index_cache', {})
+        c = cache.get(name)
         if c is None or c[0] != key:
-            object.__setattr__(self, '_feat_cache', (key, t.to(torch.int32).contiguous()))
-        return self._feat_cache[1]
+            c = cache[name] = (key, t.to(torch.int32).contiguous())
+        return c[1]
+
+    def _feat_index(self):
+        return self._index32('transform_features')
 
     def _run(self, inputs, context, inverse):
         _check_2d(inputs, self.features)
@@ -379,8 +383,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         """The conditioner's final Linear + the spline run as one launch (nf_coupling_rqs_fwd) when the
         conditioner is this package's ResidualNet in inference mode and the spline shape fits the kernel."""
         net = self.transform_net
-        return (isinstance(net, ResidualNet) and not net.training
-                and not (torch.is_grad_enabled() and inputs.requires_grad)
+        return (isinstance(net, ResidualNet) and not net.records_grad(inputs)
                 and self.tails in (None, 'linear')
                 and _lib.made_rqs_supported(self.num_bins, self.tails, net.hidden_features))
 
@@ -391,7 +394,10 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         if not inputs.is_contiguous():
             inputs = inputs.contiguous()
         net = self.transform_net
-        hidden = net.forward_hidden(inputs[:, self.identity_features].contiguous(), context)
+        if net.hidden_stack_fusable(inputs, context):
+            hidden = net.forward_hidden_columns(inputs, self._index32('identity_features'))
+        else:
+            hidden = net.forward_hidden(inputs[:, self.identity_features].contiguous(), context)
         pf = net.final_layer._packed_fused_final(self.num_transform_features, self.num_bins, self.tails,
                                                  logit_div=self._pre_div())
         outputs = inputs.clone()                       # identity columns pass through

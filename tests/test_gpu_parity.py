@@ -412,7 +412,7 @@ def test_rq_coupling_fused_equals_two_kernel_route(nf, tails, B):
         mask, lambda i, o: nf.ResidualNet(i, o, hidden_features=Hn, num_blocks=2), num_bins=8, tails=tails,
         tail_bound=2.5 if tails else 1.0).cuda().eval()
     for p in layer.parameters():
-        p.data.mul_(3.0)
+        p.data.mul_(2.0)
     x = torch.randn(B, D, device='cuda') if tails else torch.rand(B, D, device='cuda')
     from oracle import nf_oracle as O
     sd32 = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
@@ -429,6 +429,40 @@ def test_rq_coupling_fused_equals_two_kernel_route(nf, tails, B):
                 assert_close(got[0], r64[0], r32[0])
                 assert_close(got[1], r64[1], r32[1])
             assert bins.shape == (B, layer.num_transform_features) and int(bins.max()) <= 7
+
+
+@pytest.mark.parametrize('n_in,hidden,nb,bn', [(5, 32, 2, False), (32, 32, 2, True), (50, 64, 1, False),
+                                               (128, 128, 3, True), (3, 96, 0, False)])
+def test_resnet_hidden_stack_one_launch(nf, n_in, hidden, nb, bn):
+    """nf_resnet_hidden_fwd (gather + initial layer + residual blocks in LDS) against the layer-by-layer
+    route and the oracle's ResidualNet in fp64, with scattered input columns and a ragged batch."""
+    from oracle import nf_oracle as O
+    torch.manual_seed(11)
+    width = n_in + 7
+    net = nf.ResidualNet(n_in, 12, hidden_features=hidden, num_blocks=nb, use_batch_norm=bn)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    for blk in net.blocks:                       # lift the near-zero init so the blocks matter
+        blk.linear_layers[1].weight.data.normal_(0, 0.2)
+    net = net.cuda().eval()
+    cols = torch.randperm(width)[:n_in].sort().values
+    x = torch.randn(777, width, device='cuda')
+    with torch.no_grad():
+        assert net.hidden_stack_fusable(x)
+        h = net.forward_hidden_columns(x, cols.to(torch.int32).cuda())
+        h0 = net.forward_hidden(x[:, cols.cuda()].contiguous())
+        out = net.final_layer(h)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    r32 = O.residual_net_forward({'transform_net.' + k: v for k, v in sd.items()}, x.cpu()[:, cols])
+    r64 = O.residual_net_forward({'transform_net.' + k: v for k, v in sd64.items()}, x.cpu().double()[:, cols])
+    assert rel_err(h.cpu(), h0.cpu().double()) < TOL
+    assert_close(out, r64, r32)
+    assert net.forward_hidden_columns(x[:0], cols.to(torch.int32).cuda()).shape == (0, hidden)
 
 
 def test_affine_coupling_golden(nf):
