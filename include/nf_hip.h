@@ -34,6 +34,8 @@ extern "C" {
 
 #define NF_DTYPE_F32 0      /* v_mfma_f32_32x32x2_f32: exact fp32 products (1e-5 contract) */
 #define NF_DTYPE_BF16 1     /* v_mfma_f32_32x32x16_bf16 on bf16-rounded operands (2e-2 contract) */
+#define NF_DTYPE_BF16X3 2   /* fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate: fp32-level
+                             * accuracy (1e-5 contract) on the bf16 matrix pipe; nf_made_rqs_* / nf_coupling_rqs_fwd only */
 
 #define NF_AFFINE_INTERLEAVED 0 /* params[b,2d]=unconstrained scale, [b,2d+1]=shift  (transforms.py:561-566) */
 #define NF_AFFINE_BLOCKED 1     /* params[b,d]=shift, params[b,D+d]=unconstrained scale (transforms.py:328-333) */

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get('NF_HIP_LIB') or os.path.join(_HERE, 'libnf_hip.so')
 
 NF_DTYPE_F32 = 0
 NF_DTYPE_BF16 = 1
+NF_DTYPE_BF16X3 = 2
 NF_AFFINE_INTERLEAVED = 0
 NF_AFFINE_BLOCKED = 1
 NF_ERR_BINS = -4

@@ -14,6 +14,7 @@
 
 #define NF_DTYPE_F32 0
 #define NF_DTYPE_BF16 1
+#define NF_DTYPE_BF16X3 2         // fp32 operands as three bf16 terms, six bf16 MFMAs per product (fused final layer only)
 
 #define NF_AFFINE_INTERLEAVED 0  // params[b, 2d] = unconstrained scale, [2d+1] = shift (autoregressive)
 #define NF_AFFINE_BLOCKED 1      // params[b, d] = shift, params[b, D+d] = unconstrained scale (coupling)

@@ -40,7 +40,6 @@ constexpr int KPAD = 64;                // packed weight rows are padded to this
 constexpr int HR = 32;                  // epilogue: samples per pass through the LDS parameter tile
 constexpr int LDT = HR + 4;             // parameter tile [columns][HR + 4], column-major: a lane's 4 consecutive
                                         // accumulator rows go out as one ds_write_b128, conflict-free
-constexpr int GROUP_M = 16;
 
 struct FusedArgs {
     const float* h;          // [M, K] conditioner hidden state
@@ -63,6 +62,7 @@ struct FusedArgs {
     int tn0;
     int feat_limit;          // features >= feat_limit are left untouched (incremental inverse); D = all
     int64_t m_tiles;
+    int group_m;             // row tiles that share a weight tile back to back (L2 reuse)
     RqsConst c;
 };
 
@@ -72,10 +72,10 @@ __device__ __forceinline__ void tile_of_block(const FusedArgs& g, int64_t& tm, i
     const int64_t q = nwg / 8, r = nwg % 8;
     const int64_t xcd = bid % 8;
     const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    const int64_t per_group = (int64_t)GROUP_M * g.n_tiles;
+    const int64_t per_group = (int64_t)g.group_m * g.n_tiles;
     const int64_t grp = wg / per_group;
-    const int64_t first_m = grp * GROUP_M;
-    const int64_t gm = min((int64_t)GROUP_M, g.m_tiles - first_m);
+    const int64_t first_m = grp * g.group_m;
+    const int64_t gm = min((int64_t)g.group_m, g.m_tiles - first_m);
     const int64_t in = wg - grp * per_group;
     tm = first_m + in % gm;
     // heaviest column tiles first: with triangular masks the K extent grows with the tile index, and
@@ -421,6 +421,248 @@ __global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict
     }
 }
 
+// ======================================================================================================
+// Split-bf16 ("bf16x3") flavour: fp32 operands carried as three bf16 terms a = a0 + a1 + a2 (8 + 8 + 8
+// mantissa bits, an exact split), products formed from the six term pairs whose weight is >= 2^-16
+// (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Dropped pairs
+// are below 2^-24 relative: the result is as close to the exact product as the fp32 MFMA path's, at
+// 6 x 32 cycles per 32x32x16 block instead of 8 x 64 (2.67x fewer matrix-pipe cycles).
+//
+// Shape: a 256-thread workgroup owns 128 samples x 256 parameter columns (11 whole features at P = 23);
+// each of its 4 waves holds a 128 x 64 accumulator (4 x 2 MFMA tiles, 128 VGPRs), two workgroups per CU.
+// Weights are split once at pack time ([tile][16-wide K step][term][256 rows][16] bf16: one contiguous
+// 24 KB chunk per step); the hidden state is split on its way into LDS.  Epilogue as in the fp32 kernel,
+// 64 samples per pass.
+constexpr int XM = 128, XT = 256, XS = 16;     // samples per workgroup, threads, K elements per step
+constexpr int XLD = 24;                        // LDS row: 16 bf16 + 8 pad = 48 B, conflict-free ds_read_b128
+constexpr int XA = XM * XLD, XB = FN * XLD;    // bf16 elements per term plane
+constexpr int XSTAGE_BYTES = 2 * 3 * (XA + XB);
+constexpr int XHR = 64, XLDT = XHR + 4;        // epilogue pass and its column-major tile stride
+constexpr int XUNITS = 3 * FN * XS / 8;        // 16-byte units of one packed weight step (1536)
+
+__device__ __forceinline__ void split3(const float4& lo, const float4& hi, bool live, bf16x8& t0, bf16x8& t1, bf16x8& t2) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = live ? v[j] : 0.f;
+        const __bf16 h = (__bf16)a;
+        const float r1 = a - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        t0[j] = h;
+        t1[j] = m;
+        t2[j] = (__bf16)r2;
+    }
+}
+
+template <int KT, bool INV>
+__global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int fpt = g.fpt, P = g.c.P;
+    const int ncol = fpt * P;
+    __bf16* sA = (__bf16*)lds;                       // [3][128][24]
+    __bf16* sB = sA + 3 * XA;                        // [3][256][24]
+    float* tile = (float*)lds;                       // epilogue: [ncol][XLDT], aliases the staging planes
+    float* xs = (float*)(lds + max(XSTAGE_BYTES, ncol * XLDT * 4));   // [128][fpt]
+    float* ldp = xs + XM * fpt;                      // [4 waves][128]
+
+    int64_t tm;
+    int tn;
+    tile_of_block(g, tm, tn);
+    const int64_t m0 = tm * XM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wc = tid >> 6;
+    const int f0 = tn * fpt;
+    const int fv = min(fpt, g.feat_limit - f0);
+
+    for (int i = tid; i < XM * fpt; i += XT) {
+        const int r = i / fpt, f = i - r * fpt;
+        float v = 0.f;
+        if (m0 + r < g.M && f < fv) v = g.x[(m0 + r) * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)];
+        xs[i] = v;
+    }
+
+    const int kt_begin = g.ktab[2 * tn];
+    const int kt_end = min(g.ktab[2 * tn + 1], (g.K + XS - 1) / XS);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float bv = g.bias[tn * FN + wc * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
+
+    // staging: A - thread owns 8 consecutive k of one row; B - six 16-byte units of the step's packed chunk
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const float* ap = g.h + min(m0 + arow, g.M - 1) * g.ldh;
+    const bf16x8* bp = (const bf16x8*)g.w + (int64_t)tn * (g.kpad / XS) * XUNITS + tid;
+    __bf16* asl = sA + arow * XLD + ahalf * 8;
+    __bf16* bsl = sB + (tid >> 1) * XLD + ahalf * 8;
+    float4 ra0, ra1;
+    bf16x8 rb0, rb1, rb2, rb3, rb4, rb5;
+#define X3_LOAD(kt_)                                                                  \
+    {                                                                                 \
+        const int kk_ = min((kt_) * XS + ahalf * 8, g.K - 8);                         \
+        ra0 = *reinterpret_cast<const float4*>(ap + kk_);                             \
+        ra1 = *reinterpret_cast<const float4*>(ap + kk_ + 4);                         \
+        const bf16x8* q_ = bp + (int64_t)(kt_) * XUNITS;                              \
+        rb0 = q_[0]; rb1 = q_[256]; rb2 = q_[512]; rb3 = q_[768]; rb4 = q_[1024]; rb5 = q_[1280]; \
+    }
+    if (kt_begin < kt_end) X3_LOAD(kt_begin)
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        __syncthreads();
+        {
+            bf16x8 t0, t1, t2;
+            split3(ra0, ra1, kt * XS + ahalf * 8 < g.K, t0, t1, t2);
+            *reinterpret_cast<bf16x8*>(asl) = t0;
+            *reinterpret_cast<bf16x8*>(asl + XA) = t1;
+            *reinterpret_cast<bf16x8*>(asl + 2 * XA) = t2;
+            *reinterpret_cast<bf16x8*>(bsl) = rb0;
+            *reinterpret_cast<bf16x8*>(bsl + 128 * XLD) = rb1;
+            *reinterpret_cast<bf16x8*>(bsl + XB) = rb2;
+            *reinterpret_cast<bf16x8*>(bsl + XB + 128 * XLD) = rb3;
+            *reinterpret_cast<bf16x8*>(bsl + 2 * XB) = rb4;
+            *reinterpret_cast<bf16x8*>(bsl + 2 * XB + 128 * XLD) = rb5;
+        }
+        __syncthreads();
+        X3_LOAD(min(kt + 1, kt_end - 1))
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 a[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                a[i][p] = *reinterpret_cast<const bf16x8*>(sA + p * XA + (i * 32 + frow) * XLD + fk);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b[p] = *reinterpret_cast<const bf16x8*>(sB + p * XB + (wc * 64 + j * 32 + frow) * XLD + fk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#undef X3_LOAD
+
+    // ---- epilogue: two passes of 64 samples (row blocks 2*half, 2*half + 1 of the accumulators) ------
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        {
+            const int col = wc * 64 + (lane & 31);
+            float* tp = tile + col * XLDT + 4 * (lane >> 5);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (col + j * 32 < ncol) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float4 v;
+                            if (half == 0) v = make_float4(acc[ii][j][4 * q], acc[ii][j][4 * q + 1], acc[ii][j][4 * q + 2], acc[ii][j][4 * q + 3]);
+                            else v = make_float4(acc[2 + ii][j][4 * q], acc[2 + ii][j][4 * q + 1], acc[2 + ii][j][4 * q + 2], acc[2 + ii][j][4 * q + 3]);
+                            *reinterpret_cast<float4*>(tp + j * 32 * XLDT + ii * 32 + 8 * q) = v;
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        float lsum = 0.f;                            // lane = sample row of the pass, wave-uniform feature
+        const int r = half * XHR + lane;
+        for (int f = wc; f < fv; f += XT / 64) {
+            float yv, ld;
+            int bin;
+            rqs_eval<KT, INV, XLDT, true>(tile + f * P * XLDT + lane, xs[r * fpt + f], g.c, yv, ld, bin);
+            xs[r * fpt + f] = yv;
+            lsum += ld;
+            if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + f] = bin;
+        }
+        ldp[wc * XM + r] = lsum;
+    }
+    __syncthreads();
+    if (tid < XM) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < XT / 64; ++w) s += ldp[w * XM + tid];
+        if (m0 + tid < g.M) g.partial[(int64_t)tn * g.M + m0 + tid] = s;
+    }
+    for (int i = tid; i < XM * fpt; i += XT) {
+        const int r = i / fpt, f = i - r * fpt;
+        if (m0 + r < g.M && f < fv) g.y[(m0 + r) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = xs[i];
+    }
+}
+
+// packed[tile][step][term][row][16]: term t of W[n][k] * mask * fold, n = tile*src_rows + row, k = step*16 + kk
+__global__ void pack_fused_x3_kernel(const float* __restrict__ W, const float* __restrict__ mask,
+                                     const float* __restrict__ bias, int out, int in, int src_rows, int kpad,
+                                     int64_t total, int P, int n_logits, float logit_fold,
+                                     __bf16* __restrict__ packed, float* __restrict__ bias_packed) {
+    const int nsteps = kpad / XS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % XS);
+        const int j = (int)((i / XS) % FN);
+        const int term = (int)((i / (XS * FN)) % 3);
+        const int step = (int)((i / (3 * XS * FN)) % nsteps);
+        const int tn = (int)(i / ((int64_t)3 * XS * FN * nsteps));
+        const int k = step * XS + kk;
+        const int64_t n = (int64_t)tn * src_rows + j;
+        const bool live = j < src_rows && n < out;
+        const float fold = (j % P) < n_logits ? logit_fold : 1.0f;
+        float v = 0.0f;
+        if (live && k < in) {
+            v = W[n * in + k];
+            if (mask) v *= mask[n * in + k];
+            v *= fold;
+        }
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        packed[i] = term == 0 ? h : (term == 1 ? m : l);
+        if (k == 0 && term == 0) bias_packed[tn * FN + j] = (live && bias) ? bias[n] * fold : 0.0f;
+    }
+}
+
+inline size_t lds_bytes_x3(int fpt, int P) {
+    const size_t tile = sizeof(float) * (size_t)fpt * P * XLDT;
+    return (tile > (size_t)XSTAGE_BYTES ? tile : (size_t)XSTAGE_BYTES) + sizeof(float) * ((size_t)XM * fpt + (size_t)XM * (XT / 64));
+}
+
+template <int KT, bool INV>
+int launch_one_x3(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)made_rqs_x3_kernel<KT, INV>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((made_rqs_x3_kernel<KT, INV>), dim3(grid), dim3(XT), lds, s, g);
+    return nf_launch_status();
+}
+
+template <bool INV>
+int launch_k_x3(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+    switch (g.c.K) {
+        case 4: return launch_one_x3<4, INV>(g, grid, lds, s);
+        case 8: return launch_one_x3<8, INV>(g, grid, lds, s);
+        case 10: return launch_one_x3<10, INV>(g, grid, lds, s);
+        default: return launch_one_x3<0, INV>(g, grid, lds, s);
+    }
+}
+
 inline int kpad_of(int in) { return (in + KPAD - 1) / KPAD * KPAD; }
 inline int fpt_of(int P) { return FN / P; }
 inline bool fused_supported(int K, int tails) {   // (and the hidden width must be a multiple of 8)
@@ -470,7 +712,7 @@ extern "C" int nf_made_rqs_tiles(int features, int K, int tails) {
 extern "C" size_t nf_made_rqs_packed_bytes(int features, int in, int K, int tails, int dtype) {
     const int nt = nf_made_rqs_tiles(features, K, tails);
     if (nt == 0 || in <= 0) return 0;
-    return (size_t)nt * FN * kpad_of(in) * (dtype == NF_DTYPE_BF16 ? 2 : 4);
+    return (size_t)nt * FN * kpad_of(in) * (dtype == NF_DTYPE_BF16 ? 2 : dtype == NF_DTYPE_BF16X3 ? 6 : 4);
 }
 
 extern "C" size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, int tails) {
@@ -484,13 +726,16 @@ extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const 
     if (!W || !packed || !bias_packed) return NF_ERR_NULL;     // ktab == NULL: keep the caller's table
     if (features <= 0 || in <= 0 || !fused_supported(K, tails) || !(logit_div > 0.0)) return NF_ERR_SHAPE;
     const float logit_fold = (float)(1.4426950408889634 / logit_div);
-    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
+    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && dtype != NF_DTYPE_BF16X3) return NF_ERR_DTYPE;
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
     const int fpt = fpt_of(P), nt = (features + fpt - 1) / fpt, out = features * P, kpad = kpad_of(in);
     const int64_t total = (int64_t)nt * FN * kpad;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == NF_DTYPE_F32)
+    if (dtype == NF_DTYPE_BF16X3)
+        hipLaunchKernelGGL(pack_fused_x3_kernel, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
+                           3 * total, P, 2 * K, logit_fold, (__bf16*)packed, bias_packed);
+    else if (dtype == NF_DTYPE_F32)
         hipLaunchKernelGGL(pack_fused_kernel<float>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
                            total, P, 2 * K, logit_fold, (float*)packed, bias_packed);
     else
@@ -514,7 +759,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
                           int tile_count, int feat_limit, int reduce, void* stream) {
     if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
-    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16) return NF_ERR_DTYPE;
+    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && dtype != NF_DTYPE_BF16X3) return NF_ERR_DTYPE;
     if (B == 0) return NF_OK;
     if (!h || !packed_w || !ktab || !bias_packed || !x || !y || !logabsdet || !workspace) return NF_ERR_NULL;
     if (h_row_stride < in || x_row_stride < row_width || y_row_stride < row_width) return NF_ERR_LAYOUT;
@@ -533,15 +778,19 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     g.n_tiles = tile_count;
     g.tn0 = tile_begin;
     g.feat_limit = feat_limit;
-    g.m_tiles = (B + FM - 1) / FM;
+    const bool x3 = dtype == NF_DTYPE_BF16X3;
+    g.m_tiles = x3 ? (B + XM - 1) / XM : (B + FM - 1) / FM;
+    g.group_m = x3 ? 8 : 16;
     const int64_t grid = g.m_tiles * g.n_tiles;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    const size_t lds = lds_bytes(g.fpt, g.c.P);
+    const size_t lds = x3 ? lds_bytes_x3(g.fpt, g.c.P) : lds_bytes(g.fpt, g.c.P);
     if (lds > 160 * 1024) return NF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     int rc = NF_OK;
     if (grid > 0) {
-        if (dtype == NF_DTYPE_BF16)
+        if (x3)
+            rc = inverse ? launch_k_x3<true>(g, (int)grid, lds, s) : launch_k_x3<false>(g, (int)grid, lds, s);
+        else if (dtype == NF_DTYPE_BF16)
             rc = inverse ? launch_k<true, true>(g, (int)grid, lds, s) : launch_k<true, false>(g, (int)grid, lds, s);
         else
             rc = inverse ? launch_k<false, true>(g, (int)grid, lds, s) : launch_k<false, false>(g, (int)grid, lds, s);

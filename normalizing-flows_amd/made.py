@@ -16,12 +16,15 @@ from torch.nn import functional as F, init
 
 from . import _lib
 
-_MATMUL_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16}
+_MATMUL_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_BF16X3}
+# the hidden-layer GEMMs have no split-bf16 kernel yet: they stay on the fp32 matrix path in that mode
+_GEMM_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_F32}
 _default_matmul = 'f32'
 
 
 def set_matmul_dtype(name):
-    """'f32' (exact fp32 MFMA, the 1e-5 contract) or 'bf16' (bf16 MFMA, the 2e-2 contract)."""
+    """'f32' (exact fp32 MFMA, the 1e-5 contract), 'bf16' (bf16 MFMA, the 2e-2 contract) or 'bf16x3' (the
+    fused final layer on six bf16 MFMAs per product of three-term split fp32 operands: the 1e-5 contract)."""
     global _default_matmul
     if name not in _MATMUL_DTYPE:
         raise ValueError('matmul dtype must be one of %s' % sorted(_MATMUL_DTYPE))
@@ -66,7 +69,7 @@ class _PackedMixin:
         cached = getattr(self, '_pack_cache', None)
         if cached is None or cached[0] != key:
             same_mask = cached is not None and cached[0][-1] == mkey      # then the K-tile table is still valid
-            pl = _lib.PackedLinear(self.weight, mask, self.bias, _MATMUL_DTYPE[get_matmul_dtype()],
+            pl = _lib.PackedLinear(self.weight, mask, self.bias, _GEMM_DTYPE[get_matmul_dtype()],
                                    reuse=cached[1] if same_mask else None)
             object.__setattr__(self, '_pack_cache', (key, pl))
             cached = self._pack_cache

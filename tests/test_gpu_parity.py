@@ -45,7 +45,7 @@ def assert_close(got, ref64, ref32=None, tol=TOL, mult=4.0):
     e = (got - ref64).abs() / ref64.abs().clamp_min(1.0)
     floor = 0.0 if ref32 is None else rel_err(torch.as_tensor(ref32).reshape(-1), ref64)
     assert e.max().item() <= max(tol, mult * floor), (e.max().item(), floor)
-    if e.numel() >= 100:
+    if e.numel() >= 1000:          # (on a [B]-sized vector the 99 % quantile is the max again)
         q = torch.quantile(e, 0.99).item()
         qref = 0.0
         if ref32 is not None:
@@ -354,6 +354,33 @@ def test_bf16_mode_cfg3_within_2e_2(nf):
     assert torch.quantile(e, 0.999).item() < 2e-2 and e.max().item() < 5e-2
     print('bf16 mode: log_prob rel err %.2e, y rel err %.2e' % (rel_err(logp.cpu(), fx['logp64']),
                                                                rel_err(y.cpu(), fx['y64'])))
+
+
+# ------------------------------------------------------------------------------- split-bf16 mode
+@pytest.mark.parametrize('case', ['small', 'cfg3', 'roundtrip', 'incremental_inverse', 'coupling_linear',
+                                  'coupling_notails', 'coupling_routes'])
+def test_bf16x3_mode_meets_the_fp32_contract(nf, case):
+    """'bf16x3': the fused final layer on six bf16 MFMAs per product of three-term split fp32 operands.
+    Same fixtures and the same 1e-5 bars as the exact-fp32 path (the tests above, re-run in that mode)."""
+    nf.set_matmul_dtype('bf16x3')
+    try:
+        if case == 'small':
+            test_rq_ar_small_golden(nf)
+        elif case == 'cfg3':
+            test_rq_ar_cfg3_golden(nf)
+        elif case == 'roundtrip':
+            test_rq_ar_roundtrip_and_chunking(nf)
+        elif case == 'incremental_inverse':
+            test_rq_ar_incremental_inverse_equals_d_pass_loop(nf)
+        elif case == 'coupling_linear':
+            test_rq_coupling_golden(nf, 'linear')
+        elif case == 'coupling_notails':
+            test_rq_coupling_golden(nf, 'notails')
+        else:
+            for B in (1, 63, 1000):
+                test_rq_coupling_fused_equals_two_kernel_route(nf, 'linear', B)
+    finally:
+        nf.set_matmul_dtype('f32')
 
 
 # ------------------------------------------------------------------------------- affine / coupling
