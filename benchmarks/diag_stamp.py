@@ -25,7 +25,8 @@ with torch.no_grad():
     out = t._transform_rows(x, x, None, torch.empty_like(x), None, False, want_bins=True)
 torch.cuda.synchronize()
 bins = out[2]
-m_tiles = (B + 63) // 64
+mode = sys.argv[2] if len(sys.argv) > 2 else 'f32'
+m_tiles = (B + 127) // 128 if mode == 'bf16x3' else (B + 63) // 64
 WAVES = 4
 n_tiles = (D + 10) // 11
 grid = m_tiles * n_tiles

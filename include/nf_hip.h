@@ -116,6 +116,9 @@ int nf_made_rqs_tiles(int features, int K, int tails);
 size_t nf_made_rqs_packed_bytes(int features, int in, int K, int tails, int dtype);
 /* fp32 scratch for the per-tile logdet partial sums: tiles * B floats. */
 size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, int tails);
+/* Same for a given dtype: NF_DTYPE_BF16X3 adds room for the hidden state split into three bf16 planes
+ * (3 * B * ceil16(in) * 2 bytes); with only nf_made_rqs_workspace_bytes the kernel splits on the fly. */
+size_t nf_made_rqs_workspace_bytes_dtype(int64_t B, int features, int in, int K, int tails, int dtype);
 /* Packs the final layer W[features*P, in] (mask folded, rows regrouped to whole features per tile),
  * its K-tile table (2*tiles int32) and its bias (tiles*256 floats). */
 int nf_made_rqs_pack(const float* W, const float* mask, const float* bias, int features, int in, int K,

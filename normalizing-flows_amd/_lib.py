@@ -54,6 +54,7 @@ _SIGNATURES = {
     'nf_made_rqs_tiles': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_made_rqs_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'nf_made_rqs_workspace_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
+    'nf_made_rqs_workspace_bytes_dtype': (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'nf_made_rqs_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                     _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'nf_made_rqs_pack_scaled': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
@@ -308,8 +309,11 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
         logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
         accumulate = False
     bins = torch.empty((B, pf.features), dtype=torch.int32, device=x.device) if want_bins else None
-    ws = workspace if workspace is not None else torch.empty(max(1, pf.tiles * B), dtype=torch.float32,
-                                                              device=x.device)
+    if workspace is None:
+        need = lib.nf_made_rqs_workspace_bytes_dtype(B, pf.features, pf.inp, pf.K, pf.tails,
+                                                      pf.dtype if tiles is None else NF_DTYPE_F32)
+        workspace = torch.empty(max(1, (need + 3) // 4), dtype=torch.float32, device=x.device)
+    ws = workspace
     tb, tc = (0, pf.tiles) if tiles is None else tiles
     fl = pf.features if feat_limit is None else feat_limit
 

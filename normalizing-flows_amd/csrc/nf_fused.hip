@@ -55,6 +55,8 @@ struct FusedArgs {
     float* partial;          // [n_tiles][M]
     int32_t* bins;           // nullable [M, D]
     const int32_t* feat_index;   // nullable [D]: column of x / y that holds feature f (coupling layers)
+    const void* hp;          // bf16x3 full launches: h pre-split into three bf16 term planes [3][M][hp_ld]
+    int64_t hp_ld;
     int64_t M;
     int K, D;
     int fpt;                 // features per tile
@@ -455,7 +457,7 @@ __device__ __forceinline__ void split3(const float4& lo, const float4& hi, bool 
     }
 }
 
-template <int KT, bool INV>
+template <int KT, bool INV, bool PRE>
 __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int fpt = g.fpt, P = g.c.P;
@@ -496,8 +498,12 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
     }
 
     // staging: A - thread owns 8 consecutive k of one row; B - six 16-byte units of the step's packed chunk
+    // (PRE: the hidden state arrives already split into term planes, zero padded to whole steps)
     const int arow = tid >> 1, ahalf = tid & 1;
     const float* ap = g.h + min(m0 + arow, g.M - 1) * g.ldh;
+    const __bf16* app = (const __bf16*)g.hp + min(m0 + arow, g.M - 1) * g.hp_ld + ahalf * 8;
+    const int64_t aplane = g.M * g.hp_ld;
+    bf16x8 rp0, rp1, rp2;
     const bf16x8* bp = (const bf16x8*)g.w + (int64_t)tn * (g.kpad / XS) * XUNITS + tid;
     __bf16* asl = sA + arow * XLD + ahalf * 8;
     __bf16* bsl = sB + (tid >> 1) * XLD + ahalf * 8;
@@ -505,19 +511,31 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
     bf16x8 rb0, rb1, rb2, rb3, rb4, rb5;
 #define X3_LOAD(kt_)                                                                  \
     {                                                                                 \
-        const int kk_ = min((kt_) * XS + ahalf * 8, g.K - 8);                         \
-        ra0 = *reinterpret_cast<const float4*>(ap + kk_);                             \
-        ra1 = *reinterpret_cast<const float4*>(ap + kk_ + 4);                         \
+        if (PRE) {                                                                    \
+            rp0 = *reinterpret_cast<const bf16x8*>(app + (kt_) * XS);                 \
+            rp1 = *reinterpret_cast<const bf16x8*>(app + aplane + (kt_) * XS);        \
+            rp2 = *reinterpret_cast<const bf16x8*>(app + 2 * aplane + (kt_) * XS);    \
+        } else {                                                                      \
+            const int kk_ = min((kt_) * XS + ahalf * 8, g.K - 8);                     \
+            ra0 = *reinterpret_cast<const float4*>(ap + kk_);                         \
+            ra1 = *reinterpret_cast<const float4*>(ap + kk_ + 4);                     \
+        }                                                                             \
         const bf16x8* q_ = bp + (int64_t)(kt_) * XUNITS;                              \
         rb0 = q_[0]; rb1 = q_[256]; rb2 = q_[512]; rb3 = q_[768]; rb4 = q_[1024]; rb5 = q_[1280]; \
     }
     if (kt_begin < kt_end) X3_LOAD(kt_begin)
     const int frow = lane & 31, fk = (lane >> 5) * 8;
+#ifdef NF_STAMP
+    long long tA = 0, tS = 0, tB = 0, tL = 0, tM = 0, tE = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, t0 = clock64(), t1;
+    const long long tstart = t0;
+#endif
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         __syncthreads();
+        STAMP(tA)
         {
             bf16x8 t0, t1, t2;
-            split3(ra0, ra1, kt * XS + ahalf * 8 < g.K, t0, t1, t2);
+            if (PRE) { t0 = rp0; t1 = rp1; t2 = rp2; }
+            else split3(ra0, ra1, kt * XS + ahalf * 8 < g.K, t0, t1, t2);
             *reinterpret_cast<bf16x8*>(asl) = t0;
             *reinterpret_cast<bf16x8*>(asl + XA) = t1;
             *reinterpret_cast<bf16x8*>(asl + 2 * XA) = t2;
@@ -528,15 +546,21 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
             *reinterpret_cast<bf16x8*>(bsl + 2 * XB) = rb4;
             *reinterpret_cast<bf16x8*>(bsl + 2 * XB + 128 * XLD) = rb5;
         }
+        STAMP(tS)
         __syncthreads();
-        X3_LOAD(min(kt + 1, kt_end - 1))
-        __builtin_amdgcn_sched_barrier(0);
+        STAMP(tB)
+        // next step's operands: one 16-byte load in front of each group of six MFMAs, so that the loads
+        // trickle into the texture path under the matrix work instead of queueing there all at once
+        const int ktn = min(kt + 1, kt_end - 1);
+        const int kkn = min(ktn * XS + ahalf * 8, g.K - 8);
+        const bf16x8* qn = bp + (int64_t)ktn * XUNITS;
         bf16x8 a[4][3];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 a[i][p] = *reinterpret_cast<const bf16x8*>(sA + p * XA + (i * 32 + frow) * XLD + fk);
+        STAMP(tL)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             bf16x8 b[3];
@@ -545,14 +569,37 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
                 b[p] = *reinterpret_cast<const bf16x8*>(sB + p * XB + (wc * 64 + j * 32 + frow) * XLD + fk);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                switch (j * 4 + i) {
+                    case 0:
+                        if (PRE) {
+                            rp0 = *reinterpret_cast<const bf16x8*>(app + ktn * XS);
+                            rp1 = *reinterpret_cast<const bf16x8*>(app + aplane + ktn * XS);
+                        } else {
+                            ra0 = *reinterpret_cast<const float4*>(ap + kkn);
+                        }
+                        break;
+                    case 1:
+                        if (PRE) rp2 = *reinterpret_cast<const bf16x8*>(app + 2 * aplane + ktn * XS);
+                        else ra1 = *reinterpret_cast<const float4*>(ap + kkn + 4);
+                        break;
+                    case 2: rb0 = qn[0]; break;
+                    case 3: rb1 = qn[256]; break;
+                    case 4: rb2 = qn[512]; break;
+                    case 5: rb3 = qn[768]; break;
+                    case 6: rb4 = qn[1024]; break;
+                    default: rb5 = qn[1280]; break;
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP(tM)
     }
 #undef X3_LOAD
 
@@ -560,6 +607,7 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
+        STAMP(e0)
         {
             const int col = wc * 64 + (lane & 31);
             float* tp = tile + col * XLDT + 4 * (lane >> 5);
@@ -579,17 +627,34 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
                 }
         }
         __syncthreads();
+        STAMP(e1)
         float lsum = 0.f;                            // lane = sample row of the pass, wave-uniform feature
         const int r = half * XHR + lane;
-        for (int f = wc; f < fv; f += XT / 64) {
-            float yv, ld;
-            int bin;
-            rqs_eval<KT, INV, XLDT, true>(tile + f * P * XLDT + lane, xs[r * fpt + f], g.c, yv, ld, bin);
-            xs[r * fpt + f] = yv;
-            lsum += ld;
-            if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + f] = bin;
+        // a wave's (up to) three features of the pass in one straight-line block: the evaluations are
+        // independent dependency chains that the scheduler interleaves (one wave per SIMD has no other ILP)
+        constexpr int NU = 3;
+        for (int fb = wc; fb < fv; fb += NU * (XT / 64)) {
+            float yv[NU], ld[NU];
+            int bin[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int f = min(fb + u * (XT / 64), fv - 1);
+                rqs_eval<KT, INV, XLDT, true, true>(tile + f * P * XLDT + lane, xs[r * fpt + f], g.c, yv[u], ld[u], bin[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int f = fb + u * (XT / 64);
+                if (f < fv) {
+                    xs[r * fpt + f] = yv[u];
+                    lsum += ld[u];
+#ifndef NF_STAMP
+                    if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + f] = bin[u];
+#endif
+                }
+            }
         }
         ldp[wc * XM + r] = lsum;
+        STAMP(e2)
     }
     __syncthreads();
     if (tid < XM) {
@@ -602,6 +667,14 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
         const int r = i / fpt, f = i - r * fpt;
         if (m0 + r < g.M && f < fv) g.y[(m0 + r) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = xs[i];
     }
+#ifdef NF_STAMP
+    STAMP(tE)
+    if (g.bins && lane == 0) {
+        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * (XT / 64) + wc) * 16;
+        dbg[0] = tA; dbg[1] = tS; dbg[2] = tB; dbg[3] = tL; dbg[4] = tM; dbg[5] = tE; dbg[6] = tstart;
+        dbg[7] = kt_end - kt_begin; dbg[8] = e0; dbg[9] = e1; dbg[10] = e2; dbg[11] = e3;
+    }
+#endif
 }
 
 // packed[tile][step][term][row][16]: term t of W[n][k] * mask * fold, n = tile*src_rows + row, k = step*16 + kk
@@ -635,31 +708,53 @@ __global__ void pack_fused_x3_kernel(const float* __restrict__ W, const float* _
     }
 }
 
+// h[M][K] fp32 -> three bf16 term planes [3][M][kp16], kp16 = K rounded up to whole 16-wide steps (zero filled)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ h, int64_t ldh, int64_t M, int K,
+                                                           int kp16, __bf16* __restrict__ planes) {
+    const int cpr = kp16 / 8;                                  // 8-element chunks per row
+    const int64_t total = M * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cpr;
+        const int k = (int)(i - r * cpr) * 8;
+        const bool live = k < K;                               // K % 8 == 0: whole chunk in or out
+        const float* p = h + r * ldh + (live ? k : 0);
+        bf16x8 t0, t1, t2;
+        split3(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), live, t0, t1, t2);
+        __bf16* o = planes + r * kp16 + k;
+        *reinterpret_cast<bf16x8*>(o) = t0;
+        *reinterpret_cast<bf16x8*>(o + M * kp16) = t1;
+        *reinterpret_cast<bf16x8*>(o + 2 * M * kp16) = t2;
+    }
+}
+
+inline int kp16_of(int in) { return (in + XS - 1) / XS * XS; }
+inline size_t planes_bytes(int64_t B, int in) { return (size_t)3 * (size_t)B * kp16_of(in) * 2; }
+
 inline size_t lds_bytes_x3(int fpt, int P) {
     const size_t tile = sizeof(float) * (size_t)fpt * P * XLDT;
     return (tile > (size_t)XSTAGE_BYTES ? tile : (size_t)XSTAGE_BYTES) + sizeof(float) * ((size_t)XM * fpt + (size_t)XM * (XT / 64));
 }
 
-template <int KT, bool INV>
+template <int KT, bool INV, bool PRE>
 int launch_one_x3(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)made_rqs_x3_kernel<KT, INV>,
+        hipError_t e = hipFuncSetAttribute((const void*)made_rqs_x3_kernel<KT, INV, PRE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((made_rqs_x3_kernel<KT, INV>), dim3(grid), dim3(XT), lds, s, g);
+    hipLaunchKernelGGL((made_rqs_x3_kernel<KT, INV, PRE>), dim3(grid), dim3(XT), lds, s, g);
     return nf_launch_status();
 }
 
-template <bool INV>
+template <bool INV, bool PRE>
 int launch_k_x3(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
     switch (g.c.K) {
-        case 4: return launch_one_x3<4, INV>(g, grid, lds, s);
-        case 8: return launch_one_x3<8, INV>(g, grid, lds, s);
-        case 10: return launch_one_x3<10, INV>(g, grid, lds, s);
-        default: return launch_one_x3<0, INV>(g, grid, lds, s);
+        case 4: return launch_one_x3<4, INV, PRE>(g, grid, lds, s);
+        case 8: return launch_one_x3<8, INV, PRE>(g, grid, lds, s);
+        case 10: return launch_one_x3<10, INV, PRE>(g, grid, lds, s);
+        default: return launch_one_x3<0, INV, PRE>(g, grid, lds, s);
     }
 }
 
@@ -720,6 +815,12 @@ extern "C" size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, in
     return nt == 0 || B <= 0 ? 0 : sizeof(float) * (size_t)nt * (size_t)B;
 }
 
+extern "C" size_t nf_made_rqs_workspace_bytes_dtype(int64_t B, int features, int in, int K, int tails, int dtype) {
+    const size_t base = nf_made_rqs_workspace_bytes(B, features, K, tails);
+    if (base == 0 || dtype != NF_DTYPE_BF16X3 || in <= 0) return base;
+    return (base + 255) / 256 * 256 + planes_bytes(B, in);       // + the hidden state as three bf16 term planes
+}
+
 extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const float* bias, int features, int in,
                                        int K, int tails, int dtype, double logit_div, void* packed, int32_t* ktab,
                                        float* bias_packed, void* stream) {
@@ -770,7 +871,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     FusedArgs g;
     g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
-    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
@@ -788,8 +889,23 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     hipStream_t s = (hipStream_t)stream;
     int rc = NF_OK;
     if (grid > 0) {
-        if (x3)
-            rc = inverse ? launch_k_x3<true>(g, (int)grid, lds, s) : launch_k_x3<false>(g, (int)grid, lds, s);
+        if (x3) {
+            // whole-layer launches split the hidden state once (72 column tiles re-read it); the windowed
+            // launches of the incremental inverse split it on the way into LDS instead
+            const size_t part = (nf_made_rqs_workspace_bytes(B, features, K, tails) + 255) / 256 * 256;
+            const bool pre = tile_count == all_tiles && workspace_bytes >= part + planes_bytes(B, in);
+            if (pre) {
+                g.hp = (const char*)workspace + part;
+                g.hp_ld = kp16_of(in);
+                const int64_t chunks = B * (g.hp_ld / 8);
+                const int sgrid = (int)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
+                hipLaunchKernelGGL(split_planes_kernel, dim3(sgrid), dim3(256), 0, s, h, h_row_stride, B, in,
+                                   (int)g.hp_ld, (__bf16*)g.hp);
+                rc = inverse ? launch_k_x3<true, true>(g, (int)grid, lds, s) : launch_k_x3<false, true>(g, (int)grid, lds, s);
+            } else {
+                rc = inverse ? launch_k_x3<true, false>(g, (int)grid, lds, s) : launch_k_x3<false, false>(g, (int)grid, lds, s);
+            }
+        }
         else if (dtype == NF_DTYPE_BF16)
             rc = inverse ? launch_k<true, true>(g, (int)grid, lds, s) : launch_k<true, false>(g, (int)grid, lds, s);
         else

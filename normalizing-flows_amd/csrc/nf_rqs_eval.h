@@ -99,11 +99,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // the fused kernel keeps its parameter tile feature-major, one row of samples per parameter).
 // BASE2: the width / height logits arrive already multiplied by log2(e) (folded into the weights that
 // produced them), so the softmax exponentials are bare exp2 instructions.
-template <int KT, bool INV, int STRIDE = 1, bool BASE2 = false>
+// STRAIGHT: no early exit for tail elements (they are evaluated at the interval centre and replaced by
+// the identity at the end), so that several evaluations inlined back to back form one basic block the
+// scheduler can interleave.
+template <int KT, bool INV, int STRIDE = 1, bool BASE2 = false, bool STRAIGHT = false>
 __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, const RqsConst& a,
                                          float& y, float& ld, int& bin) {
     const int K = KT > 0 ? KT : a.K;
-    if (a.tails && !(x >= a.left && x <= a.right)) {   // linear tails: identity, logdet 0 (NaN lands here too)
+    const bool outside = a.tails && !(x >= a.left && x <= a.right);   // linear tails: identity, logdet 0 (NaN too)
+    const float x_in = x;
+    if (STRAIGHT) {
+        x = outside ? 0.5f * (a.left + a.right) : x;
+    } else if (outside) {
         y = x;
         ld = 0.0f;
         bin = -1;
@@ -209,6 +216,11 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
     const float dnum = (s * s) * (d1 * (t * t) + 2.0f * s * t1mt + d0 * (omt * omt));
     const float l = nf_log(dnum) - 2.0f * nf_log(den);
     ld = INV ? -l : l;
+    if (STRAIGHT && outside) {
+        y = x_in;
+        ld = 0.0f;
+        bin = -1;
+    }
 }
 
 
