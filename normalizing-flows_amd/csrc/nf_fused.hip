@@ -432,13 +432,20 @@ __global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict
 //
 // Shape: a 256-thread workgroup owns 128 samples x 256 parameter columns (11 whole features at P = 23);
 // each of its 4 waves holds a 128 x 64 accumulator (4 x 2 MFMA tiles, 128 VGPRs), two workgroups per CU.
+// K loop: 16-wide steps, LDS double buffered, ONE barrier per step: while the 48 MFMAs of step k run,
+// the registers holding step k+1 go to the other LDS stage and the loads of step k+2 are issued, one
+// in front of each group of six MFMAs.
 // Weights are split once at pack time ([tile][16-wide K step][term][256 rows][16] bf16: one contiguous
 // 24 KB chunk per step); the hidden state is split on its way into LDS.  Epilogue as in the fp32 kernel,
 // 64 samples per pass.
 constexpr int XM = 128, XT = 256, XS = 16;     // samples per workgroup, threads, K elements per step
-constexpr int XLD = 24;                        // LDS row: 16 bf16 + 8 pad = 48 B, conflict-free ds_read_b128
+// LDS stage = three term planes of A [128 rows][32 B] and of B [256 rows][32 B], rows unpadded; the two
+// 16-byte halves of a row are swapped when bit 3 of the row is set, which makes the MFMA operand reads
+// (ds_read_b128, lane = row, lane groups {0-3,12-15,20-27}...) conflict-free.  Two stages (double buffer).
+constexpr int XLD = 16;                        // bf16 elements per LDS row
 constexpr int XA = XM * XLD, XB = FN * XLD;    // bf16 elements per term plane
-constexpr int XSTAGE_BYTES = 2 * 3 * (XA + XB);
+constexpr int XSTAGE = 3 * (XA + XB);          // bf16 elements per stage (36864 B)
+constexpr int XSTAGE_BYTES = 2 * 2 * XSTAGE;   // both stages
 constexpr int XHR = 64, XLDT = XHR + 4;        // epilogue pass and its column-major tile stride
 constexpr int XUNITS = 3 * FN * XS / 8;        // 16-byte units of one packed weight step (1536)
 
@@ -462,8 +469,7 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int fpt = g.fpt, P = g.c.P;
     const int ncol = fpt * P;
-    __bf16* sA = (__bf16*)lds;                       // [3][128][24]
-    __bf16* sB = sA + 3 * XA;                        // [3][256][24]
+    __bf16* stage0 = (__bf16*)lds;                   // stage s at stage0 + s * XSTAGE: A planes, then B planes
     float* tile = (float*)lds;                       // epilogue: [ncol][XLDT], aliases the staging planes
     float* xs = (float*)(lds + max(XSTAGE_BYTES, ncol * XLDT * 4));   // [128][fpt]
     float* ldp = xs + XM * fpt;                      // [4 waves][128]
@@ -503,92 +509,94 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
     const float* ap = g.h + min(m0 + arow, g.M - 1) * g.ldh;
     const __bf16* app = (const __bf16*)g.hp + min(m0 + arow, g.M - 1) * g.hp_ld + ahalf * 8;
     const int64_t aplane = g.M * g.hp_ld;
-    bf16x8 rp0, rp1, rp2;
     const bf16x8* bp = (const bf16x8*)g.w + (int64_t)tn * (g.kpad / XS) * XUNITS + tid;
-    __bf16* asl = sA + arow * XLD + ahalf * 8;
-    __bf16* bsl = sB + (tid >> 1) * XLD + ahalf * 8;
+    // LDS element offsets inside a stage: row * 16 + (half ^ bit 3 of the row) * 8
+    const int woff = arow * XLD + ((ahalf ^ ((arow >> 3) & 1)) * 8);          // rows arow (A, B) and arow + 128 (B)
+    const int frow = lane & 31;
+    const int roff = frow * XLD + (((lane >> 5) ^ ((frow >> 3) & 1)) * 8);
     float4 ra0, ra1;
-    bf16x8 rb0, rb1, rb2, rb3, rb4, rb5;
-#define X3_LOAD(kt_)                                                                  \
-    {                                                                                 \
-        if (PRE) {                                                                    \
-            rp0 = *reinterpret_cast<const bf16x8*>(app + (kt_) * XS);                 \
-            rp1 = *reinterpret_cast<const bf16x8*>(app + aplane + (kt_) * XS);        \
-            rp2 = *reinterpret_cast<const bf16x8*>(app + 2 * aplane + (kt_) * XS);    \
-        } else {                                                                      \
-            const int kk_ = min((kt_) * XS + ahalf * 8, g.K - 8);                     \
-            ra0 = *reinterpret_cast<const float4*>(ap + kk_);                         \
-            ra1 = *reinterpret_cast<const float4*>(ap + kk_ + 4);                     \
-        }                                                                             \
-        const bf16x8* q_ = bp + (int64_t)(kt_) * XUNITS;                              \
-        rb0 = q_[0]; rb1 = q_[256]; rb2 = q_[512]; rb3 = q_[768]; rb4 = q_[1024]; rb5 = q_[1280]; \
+    bf16x8 rp0, rp1, rp2, rb0, rb1, rb2, rb3, rb4, rb5;
+#define X3_LOAD_PIECE(n_, kt_)                                                                        \
+    {                                                                                                 \
+        if ((n_) == 0) {                                                                              \
+            if (PRE) {                                                                                \
+                rp0 = *reinterpret_cast<const bf16x8*>(app + (kt_) * XS);                             \
+                rp1 = *reinterpret_cast<const bf16x8*>(app + aplane + (kt_) * XS);                    \
+            } else {                                                                                  \
+                ra0 = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8));    \
+            }                                                                                         \
+        } else if ((n_) == 1) {                                                                       \
+            if (PRE) rp2 = *reinterpret_cast<const bf16x8*>(app + 2 * aplane + (kt_) * XS);           \
+            else ra1 = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8) + 4); \
+        } else if ((n_) == 2) rb0 = bp[(int64_t)(kt_) * XUNITS];                                      \
+        else if ((n_) == 3) rb1 = bp[(int64_t)(kt_) * XUNITS + 256];                                  \
+        else if ((n_) == 4) rb2 = bp[(int64_t)(kt_) * XUNITS + 512];                                  \
+        else if ((n_) == 5) rb3 = bp[(int64_t)(kt_) * XUNITS + 768];                                  \
+        else if ((n_) == 6) rb4 = bp[(int64_t)(kt_) * XUNITS + 1024];                                 \
+        else rb5 = bp[(int64_t)(kt_) * XUNITS + 1280];                                                \
     }
-    if (kt_begin < kt_end) X3_LOAD(kt_begin)
-    const int frow = lane & 31, fk = (lane >> 5) * 8;
+#define X3_STORE(st_, kt_)                                                                            \
+    {                                                                                                 \
+        __bf16* sa_ = (st_) + woff;                                                                   \
+        __bf16* sb_ = (st_) + 3 * XA + woff;                                                          \
+        bf16x8 t0_, t1_, t2_;                                                                         \
+        if (PRE) { t0_ = rp0; t1_ = rp1; t2_ = rp2; }                                                 \
+        else split3(ra0, ra1, (kt_) * XS + ahalf * 8 < g.K, t0_, t1_, t2_);                           \
+        *reinterpret_cast<bf16x8*>(sa_) = t0_;                                                        \
+        *reinterpret_cast<bf16x8*>(sa_ + XA) = t1_;                                                   \
+        *reinterpret_cast<bf16x8*>(sa_ + 2 * XA) = t2_;                                               \
+        *reinterpret_cast<bf16x8*>(sb_) = rb0;                                                        \
+        *reinterpret_cast<bf16x8*>(sb_ + 128 * XLD) = rb1;                                            \
+        *reinterpret_cast<bf16x8*>(sb_ + XB) = rb2;                                                   \
+        *reinterpret_cast<bf16x8*>(sb_ + XB + 128 * XLD) = rb3;                                       \
+        *reinterpret_cast<bf16x8*>(sb_ + 2 * XB) = rb4;                                               \
+        *reinterpret_cast<bf16x8*>(sb_ + 2 * XB + 128 * XLD) = rb5;                                   \
+    }
 #ifdef NF_STAMP
     long long tA = 0, tS = 0, tB = 0, tL = 0, tM = 0, tE = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, t0 = clock64(), t1;
     const long long tstart = t0;
 #endif
+    // prologue: step 0 into stage 0, step 1 into the registers
+    if (kt_begin < kt_end) {
+        const int k1 = min(kt_begin + 1, kt_end - 1);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) X3_LOAD_PIECE(n, kt_begin)
+        X3_STORE(stage0, kt_begin)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) X3_LOAD_PIECE(n, k1)
+    }
+    __syncthreads();
+    STAMP(tS)
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        __syncthreads();
-        STAMP(tA)
-        {
-            bf16x8 t0, t1, t2;
-            if (PRE) { t0 = rp0; t1 = rp1; t2 = rp2; }
-            else split3(ra0, ra1, kt * XS + ahalf * 8 < g.K, t0, t1, t2);
-            *reinterpret_cast<bf16x8*>(asl) = t0;
-            *reinterpret_cast<bf16x8*>(asl + XA) = t1;
-            *reinterpret_cast<bf16x8*>(asl + 2 * XA) = t2;
-            *reinterpret_cast<bf16x8*>(bsl) = rb0;
-            *reinterpret_cast<bf16x8*>(bsl + 128 * XLD) = rb1;
-            *reinterpret_cast<bf16x8*>(bsl + XB) = rb2;
-            *reinterpret_cast<bf16x8*>(bsl + XB + 128 * XLD) = rb3;
-            *reinterpret_cast<bf16x8*>(bsl + 2 * XB) = rb4;
-            *reinterpret_cast<bf16x8*>(bsl + 2 * XB + 128 * XLD) = rb5;
-        }
-        STAMP(tS)
-        __syncthreads();
-        STAMP(tB)
-        // next step's operands: one 16-byte load in front of each group of six MFMAs, so that the loads
-        // trickle into the texture path under the matrix work instead of queueing there all at once
-        const int ktn = min(kt + 1, kt_end - 1);
-        const int kkn = min(ktn * XS + ahalf * 8, g.K - 8);
-        const bf16x8* qn = bp + (int64_t)ktn * XUNITS;
+        const int cur = (kt - kt_begin) & 1;
+        const __bf16* sA = stage0 + cur * XSTAGE;
+        const __bf16* sB = sA + 3 * XA;
+        __bf16* nxt = stage0 + (cur ^ 1) * XSTAGE;
+        const int kt1 = min(kt + 1, kt_end - 1), kt2 = min(kt + 2, kt_end - 1);
         bf16x8 a[4][3];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                a[i][p] = *reinterpret_cast<const bf16x8*>(sA + p * XA + (i * 32 + frow) * XLD + fk);
-        STAMP(tL)
+                a[i][p] = *reinterpret_cast<const bf16x8*>(sA + p * XA + i * 32 * XLD + roff);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             bf16x8 b[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                b[p] = *reinterpret_cast<const bf16x8*>(sB + p * XB + (wc * 64 + j * 32 + frow) * XLD + fk);
+                b[p] = *reinterpret_cast<const bf16x8*>(sB + p * XB + (wc * 64 + j * 32) * XLD + roff);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                switch (j * 4 + i) {
-                    case 0:
-                        if (PRE) {
-                            rp0 = *reinterpret_cast<const bf16x8*>(app + ktn * XS);
-                            rp1 = *reinterpret_cast<const bf16x8*>(app + aplane + ktn * XS);
-                        } else {
-                            ra0 = *reinterpret_cast<const float4*>(ap + kkn);
-                        }
-                        break;
-                    case 1:
-                        if (PRE) rp2 = *reinterpret_cast<const bf16x8*>(app + 2 * aplane + ktn * XS);
-                        else ra1 = *reinterpret_cast<const float4*>(ap + kkn + 4);
-                        break;
-                    case 2: rb0 = qn[0]; break;
-                    case 3: rb1 = qn[256]; break;
-                    case 4: rb2 = qn[512]; break;
-                    case 5: rb3 = qn[768]; break;
-                    case 6: rb4 = qn[1024]; break;
-                    default: rb5 = qn[1280]; break;
-                }
+                const int grp = j * 4 + i;
+                // group 1: the registers (step kt+1, loaded a whole step ago) go to the other stage;
+                // groups 2..7: the loads of step kt+2, spread under the matrix work
+                if (grp == 1) X3_STORE(nxt, kt1)
+                if (grp == 2) { X3_LOAD_PIECE(0, kt2) X3_LOAD_PIECE(1, kt2) }
+                if (grp == 3) { X3_LOAD_PIECE(2, kt2) }
+                if (grp == 4) { X3_LOAD_PIECE(3, kt2) }
+                if (grp == 5) { X3_LOAD_PIECE(4, kt2) }
+                if (grp == 6) { X3_LOAD_PIECE(5, kt2) X3_LOAD_PIECE(6, kt2) }
+                if (grp == 7) { X3_LOAD_PIECE(7, kt2) }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
@@ -600,8 +608,11 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
             }
         }
         STAMP(tM)
+        __syncthreads();
+        STAMP(tA)
     }
-#undef X3_LOAD
+#undef X3_STORE
+#undef X3_LOAD_PIECE
 
     // ---- epilogue: two passes of 64 samples (row blocks 2*half, 2*half + 1 of the accumulators) ------
 #pragma unroll 1
