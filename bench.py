@@ -69,7 +69,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=262144, help='samples per GPU per step')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16x3'], help='MADE matrix-core input type')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16x3', 'f16x2'], help='MADE matrix-core input type')
     ap.add_argument('--cpu-sample', type=int, default=2048)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-bf16', action='store_true', help='skip the secondary bf16-MFMA measurement')

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get('NF_HIP_LIB') or os.path.join(_HERE, 'libnf_hip.so')
 NF_DTYPE_F32 = 0
 NF_DTYPE_BF16 = 1
 NF_DTYPE_BF16X3 = 2
+NF_DTYPE_F16X2 = 3
 NF_AFFINE_INTERLEAVED = 0
 NF_AFFINE_BLOCKED = 1
 NF_ERR_BINS = -4
@@ -268,7 +269,7 @@ class PackedFusedFinal:
             raise NfError(-2, 'nf_made_rqs_tiles')
         self.packed = torch.empty(lib.nf_made_rqs_packed_bytes(self.features, self.inp, self.K, t, dtype),
                                   dtype=torch.uint8, device=w.device)
-        self.ktab = torch.empty(2 * self.tiles, dtype=torch.int32, device=w.device)
+        self.ktab = torch.zeros(2 * self.tiles + 2, dtype=torch.int32, device=w.device)   # + the f16x2 scale pair
         self.bias = torch.empty(256 * self.tiles, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
             _check(lib.nf_made_rqs_pack_scaled(w.data_ptr(), _ptr(m), _ptr(b), self.features, self.inp, self.K, t,

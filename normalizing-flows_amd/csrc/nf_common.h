@@ -14,6 +14,7 @@
 
 #define NF_DTYPE_F32 0
 #define NF_DTYPE_BF16 1
+#define NF_DTYPE_F16X2 3          // fp32 operands as two fp16 terms (weights power-of-two scaled), three fp16 MFMAs per product
 #define NF_DTYPE_BF16X3 2         // fp32 operands as three bf16 terms, six bf16 MFMAs per product (fused final layer only)
 
 #define NF_AFFINE_INTERLEAVED 0  // params[b, 2d] = unconstrained scale, [2d+1] = shift (autoregressive)

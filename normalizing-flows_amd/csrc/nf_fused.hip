@@ -55,7 +55,8 @@ struct FusedArgs {
     float* partial;          // [n_tiles][M]
     int32_t* bins;           // nullable [M, D]
     const int32_t* feat_index;   // nullable [D]: column of x / y that holds feature f (coupling layers)
-    const void* hp;          // bf16x3 full launches: h pre-split into three bf16 term planes [3][M][hp_ld]
+    const float* scale;      // f16x2: {2^e, 2^-e} weight scale pair written at pack time (after the K-range table)
+    const void* hp;          // split-operand full launches: h pre-split into three bf16 term planes [3][M][hp_ld]
     int64_t hp_ld;
     int64_t M;
     int K, D;
@@ -435,41 +436,91 @@ __global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict
 // K loop: 16-wide steps, LDS double buffered, ONE barrier per step: while the 48 MFMAs of step k run,
 // the registers holding step k+1 go to the other LDS stage and the loads of step k+2 are issued, one
 // in front of each group of six MFMAs.
-// Weights are split once at pack time ([tile][16-wide K step][term][256 rows][16] bf16: one contiguous
-// 24 KB chunk per step); the hidden state is split on its way into LDS.  Epilogue as in the fp32 kernel,
-// 64 samples per pass.
+// Weights are split once at pack time ([tile][16-wide K step][term][256 rows][16]: one contiguous chunk
+// per step); the hidden state is split by a pre-pass (whole-layer launches) or on its way into LDS.
+// Epilogue as in the fp32 kernel, 64 samples per pass.
+//
+// Split-fp16 ("f16x2") flavour of the same kernel: two fp16 terms a = a0 + a1 (11 + 11 mantissa bits),
+// three products a0b0, a0b1, a1b0 on v_mfma_f32_32x32x16_f16; the dropped a1b1 is 2^-22 relative, below
+// the fp32 accumulation error of a 512-term sum.  fp16 has 5 exponent bits, so the weights are scaled by
+// a power of two chosen at pack time (largest magnitude just under 2^14; undone exactly in the epilogue)
+// and the hidden state is taken as is: exact to 2^-25 absolute for |h| < 131008 (beyond: saturates).
+// Half the matrix work and 2/3 of the operand traffic of bf16x3 - this kernel is power-limited, not
+// issue-limited (the clock drops to ~1.7 GHz under it), so energy per product is what buys time.
 constexpr int XM = 128, XT = 256, XS = 16;     // samples per workgroup, threads, K elements per step
-// LDS stage = three term planes of A [128 rows][32 B] and of B [256 rows][32 B], rows unpadded; the two
+// LDS stage = NT term planes of A [128 rows][32 B] and of B [256 rows][32 B], rows unpadded; the two
 // 16-byte halves of a row are swapped when bit 3 of the row is set, which makes the MFMA operand reads
 // (ds_read_b128, lane = row, lane groups {0-3,12-15,20-27}...) conflict-free.  Two stages (double buffer).
-constexpr int XLD = 16;                        // bf16 elements per LDS row
-constexpr int XA = XM * XLD, XB = FN * XLD;    // bf16 elements per term plane
-constexpr int XSTAGE = 3 * (XA + XB);          // bf16 elements per stage (36864 B)
-constexpr int XSTAGE_BYTES = 2 * 2 * XSTAGE;   // both stages
+constexpr int XLD = 16;                        // 16-bit elements per LDS row
+constexpr int XA = XM * XLD, XB = FN * XLD;    // elements per term plane
 constexpr int XHR = 64, XLDT = XHR + 4;        // epilogue pass and its column-major tile stride
-constexpr int XUNITS = 3 * FN * XS / 8;        // 16-byte units of one packed weight step (1536)
 
-__device__ __forceinline__ void split3(const float4& lo, const float4& hi, bool live, bf16x8& t0, bf16x8& t1, bf16x8& t2) {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct SplitBf16x3 {
+    static constexpr int NT = 3;
+    static constexpr bool SCALED = false;
+    typedef __bf16 elem;
+    typedef bf16x8 vec;
+    static __device__ __forceinline__ void split1(float a, elem (&t)[NT]) {
+        t[0] = (__bf16)a;
+        const float r1 = a - (float)t[0];
+        t[1] = (__bf16)r1;
+        t[2] = (__bf16)(r1 - (float)t[1]);
+    }
+    static __device__ __forceinline__ void fma_tile(f32x16& acc, const vec (&a)[NT], const vec (&b)[NT]) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    }
+};
+
+struct SplitF16x2 {
+    static constexpr int NT = 2;
+    static constexpr bool SCALED = true;
+    typedef _Float16 elem;
+    typedef f16x8 vec;
+    static __device__ __forceinline__ void split1(float a, elem (&t)[NT]) {
+        float c = fminf(fmaxf(a, -65504.f), 65504.f);
+        if (a != a) c = a;                         // NaN stays NaN
+        t[0] = (_Float16)c;
+        t[1] = (_Float16)(a - (float)t[0]);
+    }
+    static __device__ __forceinline__ void fma_tile(f32x16& acc, const vec (&a)[NT], const vec (&b)[NT]) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+    }
+};
+
+template <class SP>
+__device__ __forceinline__ void split_chunk(const float4& lo, const float4& hi, bool live, typename SP::vec (&t)[SP::NT]) {
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float a = live ? v[j] : 0.f;
-        const __bf16 h = (__bf16)a;
-        const float r1 = a - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        t0[j] = h;
-        t1[j] = m;
-        t2[j] = (__bf16)r2;
+        typename SP::elem e[SP::NT];
+        SP::split1(live ? v[j] : 0.f, e);
+#pragma unroll
+        for (int p = 0; p < SP::NT; ++p) t[p][j] = e[p];
     }
 }
 
-template <int KT, bool INV, bool PRE>
-__global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
+template <class SP, int KT, bool INV, bool PRE>
+__global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g) {
+    constexpr int NT = SP::NT;
+    constexpr int XSTAGE = NT * (XA + XB);             // elements per stage
+    constexpr int XSTAGE_BYTES = 2 * 2 * XSTAGE;       // both stages
+    constexpr int XUNITS = NT * FN * XS / 8;           // 16-byte units of one packed weight step
+    constexpr int NP = 3 * NT;                         // load pieces per step: NT of A, 2 NT of B
+    typedef typename SP::vec vec;
+    typedef typename SP::elem elem;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int fpt = g.fpt, P = g.c.P;
     const int ncol = fpt * P;
-    __bf16* stage0 = (__bf16*)lds;                   // stage s at stage0 + s * XSTAGE: A planes, then B planes
+    elem* stage0 = (elem*)lds;                       // stage s at stage0 + s * XSTAGE: A planes, then B planes
     float* tile = (float*)lds;                       // epilogue: [ncol][XLDT], aliases the staging planes
     float* xs = (float*)(lds + max(XSTAGE_BYTES, ncol * XLDT * 4));   // [128][fpt]
     float* ldp = xs + XM * fpt;                      // [4 waves][128]
@@ -496,7 +547,7 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
     f32x16 acc[4][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const float bv = g.bias[tn * FN + wc * 64 + j * 32 + (lane & 31)];
+        const float bv = g.bias[tn * FN + wc * 64 + j * 32 + (lane & 31)] * (SP::SCALED ? g.scale[0] : 1.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -507,50 +558,38 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
     // (PRE: the hidden state arrives already split into term planes, zero padded to whole steps)
     const int arow = tid >> 1, ahalf = tid & 1;
     const float* ap = g.h + min(m0 + arow, g.M - 1) * g.ldh;
-    const __bf16* app = (const __bf16*)g.hp + min(m0 + arow, g.M - 1) * g.hp_ld + ahalf * 8;
+    const elem* app = (const elem*)g.hp + min(m0 + arow, g.M - 1) * g.hp_ld + ahalf * 8;
     const int64_t aplane = g.M * g.hp_ld;
-    const bf16x8* bp = (const bf16x8*)g.w + (int64_t)tn * (g.kpad / XS) * XUNITS + tid;
+    const vec* bp = (const vec*)g.w + (int64_t)tn * (g.kpad / XS) * XUNITS + tid;
     // LDS element offsets inside a stage: row * 16 + (half ^ bit 3 of the row) * 8
     const int woff = arow * XLD + ((ahalf ^ ((arow >> 3) & 1)) * 8);          // rows arow (A, B) and arow + 128 (B)
     const int frow = lane & 31;
     const int roff = frow * XLD + (((lane >> 5) ^ ((frow >> 3) & 1)) * 8);
     float4 ra0, ra1;
-    bf16x8 rp0, rp1, rp2, rb0, rb1, rb2, rb3, rb4, rb5;
+    vec rp[NT], rb[2 * NT];
 #define X3_LOAD_PIECE(n_, kt_)                                                                        \
     {                                                                                                 \
-        if ((n_) == 0) {                                                                              \
-            if (PRE) {                                                                                \
-                rp0 = *reinterpret_cast<const bf16x8*>(app + (kt_) * XS);                             \
-                rp1 = *reinterpret_cast<const bf16x8*>(app + aplane + (kt_) * XS);                    \
-            } else {                                                                                  \
-                ra0 = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8));    \
-            }                                                                                         \
-        } else if ((n_) == 1) {                                                                       \
-            if (PRE) rp2 = *reinterpret_cast<const bf16x8*>(app + 2 * aplane + (kt_) * XS);           \
-            else ra1 = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8) + 4); \
-        } else if ((n_) == 2) rb0 = bp[(int64_t)(kt_) * XUNITS];                                      \
-        else if ((n_) == 3) rb1 = bp[(int64_t)(kt_) * XUNITS + 256];                                  \
-        else if ((n_) == 4) rb2 = bp[(int64_t)(kt_) * XUNITS + 512];                                  \
-        else if ((n_) == 5) rb3 = bp[(int64_t)(kt_) * XUNITS + 768];                                  \
-        else if ((n_) == 6) rb4 = bp[(int64_t)(kt_) * XUNITS + 1024];                                 \
-        else rb5 = bp[(int64_t)(kt_) * XUNITS + 1280];                                                \
+        if ((n_) < NT) {                                                                              \
+            if (PRE) rp[(n_) < NT ? (n_) : 0] = *reinterpret_cast<const vec*>(app + (n_) * aplane + (kt_) * XS); \
+            else if ((n_) == 0) ra0 = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8));   \
+            else if ((n_) == 1) ra1 = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8) + 4); \
+        } else {                                                                                      \
+            rb[(n_) >= NT ? (n_) - NT : 0] = bp[(int64_t)(kt_) * XUNITS + 256 * ((n_) - NT)];         \
+        }                                                                                             \
     }
 #define X3_STORE(st_, kt_)                                                                            \
     {                                                                                                 \
-        __bf16* sa_ = (st_) + woff;                                                                   \
-        __bf16* sb_ = (st_) + 3 * XA + woff;                                                          \
-        bf16x8 t0_, t1_, t2_;                                                                         \
-        if (PRE) { t0_ = rp0; t1_ = rp1; t2_ = rp2; }                                                 \
-        else split3(ra0, ra1, (kt_) * XS + ahalf * 8 < g.K, t0_, t1_, t2_);                           \
-        *reinterpret_cast<bf16x8*>(sa_) = t0_;                                                        \
-        *reinterpret_cast<bf16x8*>(sa_ + XA) = t1_;                                                   \
-        *reinterpret_cast<bf16x8*>(sa_ + 2 * XA) = t2_;                                               \
-        *reinterpret_cast<bf16x8*>(sb_) = rb0;                                                        \
-        *reinterpret_cast<bf16x8*>(sb_ + 128 * XLD) = rb1;                                            \
-        *reinterpret_cast<bf16x8*>(sb_ + XB) = rb2;                                                   \
-        *reinterpret_cast<bf16x8*>(sb_ + XB + 128 * XLD) = rb3;                                       \
-        *reinterpret_cast<bf16x8*>(sb_ + 2 * XB) = rb4;                                               \
-        *reinterpret_cast<bf16x8*>(sb_ + 2 * XB + 128 * XLD) = rb5;                                   \
+        elem* sa_ = (st_) + woff;                                                                     \
+        elem* sb_ = (st_) + NT * XA + woff;                                                           \
+        vec t_[NT];                                                                                   \
+        if (PRE) {                                                                                    \
+            _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) t_[p_] = rp[p_];                        \
+        } else {                                                                                      \
+            split_chunk<SP>(ra0, ra1, (kt_) * XS + ahalf * 8 < g.K, t_);                              \
+        }                                                                                             \
+        _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) *reinterpret_cast<vec*>(sa_ + p_ * XA) = t_[p_]; \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2 * NT; ++q_)                                         \
+            *reinterpret_cast<vec*>(sb_ + (q_ >> 1) * XB + (q_ & 1) * 128 * XLD) = rb[q_];            \
     }
 #ifdef NF_STAMP
     long long tA = 0, tS = 0, tB = 0, tL = 0, tM = 0, tE = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, t0 = clock64(), t1;
@@ -560,50 +599,42 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
     if (kt_begin < kt_end) {
         const int k1 = min(kt_begin + 1, kt_end - 1);
 #pragma unroll
-        for (int n = 0; n < 8; ++n) X3_LOAD_PIECE(n, kt_begin)
+        for (int n = 0; n < NP; ++n) X3_LOAD_PIECE(n, kt_begin)
         X3_STORE(stage0, kt_begin)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) X3_LOAD_PIECE(n, k1)
+        for (int n = 0; n < NP; ++n) X3_LOAD_PIECE(n, k1)
     }
     __syncthreads();
     STAMP(tS)
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
-        const __bf16* sA = stage0 + cur * XSTAGE;
-        const __bf16* sB = sA + 3 * XA;
-        __bf16* nxt = stage0 + (cur ^ 1) * XSTAGE;
+        const elem* sA = stage0 + cur * XSTAGE;
+        const elem* sB = sA + NT * XA;
+        elem* nxt = stage0 + (cur ^ 1) * XSTAGE;
         const int kt1 = min(kt + 1, kt_end - 1), kt2 = min(kt + 2, kt_end - 1);
-        bf16x8 a[4][3];
+        vec a[4][NT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                a[i][p] = *reinterpret_cast<const bf16x8*>(sA + p * XA + i * 32 * XLD + roff);
+            for (int p = 0; p < NT; ++p)
+                a[i][p] = *reinterpret_cast<const vec*>(sA + p * XA + i * 32 * XLD + roff);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            bf16x8 b[3];
+            vec b[NT];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                b[p] = *reinterpret_cast<const bf16x8*>(sB + p * XB + (wc * 64 + j * 32) * XLD + roff);
+            for (int p = 0; p < NT; ++p)
+                b[p] = *reinterpret_cast<const vec*>(sB + p * XB + (wc * 64 + j * 32) * XLD + roff);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int grp = j * 4 + i;
                 // group 1: the registers (step kt+1, loaded a whole step ago) go to the other stage;
                 // groups 2..7: the loads of step kt+2, spread under the matrix work
                 if (grp == 1) X3_STORE(nxt, kt1)
-                if (grp == 2) { X3_LOAD_PIECE(0, kt2) X3_LOAD_PIECE(1, kt2) }
-                if (grp == 3) { X3_LOAD_PIECE(2, kt2) }
-                if (grp == 4) { X3_LOAD_PIECE(3, kt2) }
-                if (grp == 5) { X3_LOAD_PIECE(4, kt2) }
-                if (grp == 6) { X3_LOAD_PIECE(5, kt2) X3_LOAD_PIECE(6, kt2) }
-                if (grp == 7) { X3_LOAD_PIECE(7, kt2) }
+#pragma unroll
+                for (int n = 0; n < NP; ++n)
+                    if (grp == 2 + (n * 6) / NP) X3_LOAD_PIECE(n, kt2)
                 __builtin_amdgcn_sched_barrier(0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
+                SP::fma_tile(acc[i][j], a[i], b);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -615,6 +646,7 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
 #undef X3_LOAD_PIECE
 
     // ---- epilogue: two passes of 64 samples (row blocks 2*half, 2*half + 1 of the accumulators) ------
+    const float oscale = SP::SCALED ? g.scale[1] : 1.f;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
@@ -632,6 +664,7 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
                             float4 v;
                             if (half == 0) v = make_float4(acc[ii][j][4 * q], acc[ii][j][4 * q + 1], acc[ii][j][4 * q + 2], acc[ii][j][4 * q + 3]);
                             else v = make_float4(acc[2 + ii][j][4 * q], acc[2 + ii][j][4 * q + 1], acc[2 + ii][j][4 * q + 2], acc[2 + ii][j][4 * q + 3]);
+                            if (SP::SCALED) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
                             *reinterpret_cast<float4*>(tp + j * 32 * XLDT + ii * 32 + 8 * q) = v;
                         }
                     }
@@ -688,18 +721,23 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_x3_kernel(const FusedArgs g) {
 #endif
 }
 
-// packed[tile][step][term][row][16]: term t of W[n][k] * mask * fold, n = tile*src_rows + row, k = step*16 + kk
-__global__ void pack_fused_x3_kernel(const float* __restrict__ W, const float* __restrict__ mask,
-                                     const float* __restrict__ bias, int out, int in, int src_rows, int kpad,
-                                     int64_t total, int P, int n_logits, float logit_fold,
-                                     __bf16* __restrict__ packed, float* __restrict__ bias_packed) {
+// packed[tile][step][term][row][16]: term t of W[n][k] * mask * fold (* the scale slot's power of two),
+// n = tile*src_rows + row, k = step*16 + kk
+template <class SP>
+__global__ void pack_fused_split_kernel(const float* __restrict__ W, const float* __restrict__ mask,
+                                        const float* __restrict__ bias, int out, int in, int src_rows, int kpad,
+                                        int64_t total, int P, int n_logits, float logit_fold,
+                                        const float* __restrict__ scale, typename SP::elem* __restrict__ packed,
+                                        float* __restrict__ bias_packed) {
+    constexpr int NT = SP::NT;
     const int nsteps = kpad / XS;
+    const float sw = SP::SCALED ? scale[0] : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int kk = (int)(i % XS);
         const int j = (int)((i / XS) % FN);
-        const int term = (int)((i / (XS * FN)) % 3);
-        const int step = (int)((i / (3 * XS * FN)) % nsteps);
-        const int tn = (int)(i / ((int64_t)3 * XS * FN * nsteps));
+        const int term = (int)((i / (XS * FN)) % NT);
+        const int step = (int)((i / (NT * XS * FN)) % nsteps);
+        const int tn = (int)(i / ((int64_t)NT * XS * FN * nsteps));
         const int k = step * XS + kk;
         const int64_t n = (int64_t)tn * src_rows + j;
         const bool live = j < src_rows && n < out;
@@ -710,18 +748,54 @@ __global__ void pack_fused_x3_kernel(const float* __restrict__ W, const float* _
             if (mask) v *= mask[n * in + k];
             v *= fold;
         }
-        const __bf16 h = (__bf16)v;
-        const float r1 = v - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const __bf16 l = (__bf16)(r1 - (float)m);
-        packed[i] = term == 0 ? h : (term == 1 ? m : l);
+        typename SP::elem t[NT];
+        SP::split1(v * sw, t);
+        typename SP::elem o = t[0];
+#pragma unroll
+        for (int q = 1; q < NT; ++q) o = term == q ? t[q] : o;
+        packed[i] = o;
         if (k == 0 && term == 0) bias_packed[tn * FN + j] = (live && bias) ? bias[n] * fold : 0.0f;
     }
 }
 
-// h[M][K] fp32 -> three bf16 term planes [3][M][kp16], kp16 = K rounded up to whole 16-wide steps (zero filled)
+// scale slot (two floats after the K-range table): [0] = 2^e with max |W * mask * fold| * 2^e in [2^13, 2^14),
+// [1] = 2^-e.  maxabs_kernel leaves the bit pattern of the maximum in slot[0] (positive floats order like
+// unsigned integers), scale_slot_kernel turns it into the pair.
+__global__ void maxabs_kernel(const float* __restrict__ W, const float* __restrict__ mask, int64_t total, int P, int in,
+                              int n_logits, float logit_fold, unsigned* __restrict__ slot) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = W[i];
+        if (mask) v *= mask[i];
+        if ((int)((i / in) % P) < n_logits) v *= logit_fold;
+        m = fmaxf(m, fabsf(v));
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 8, 64));
+    m = fmaxf(m, __shfl_xor(m, 4, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    if ((threadIdx.x & 63) == 0 && m == m && m < INFINITY) atomicMax(slot, __float_as_uint(m));
+}
+
+__global__ void scale_slot_kernel(float* __restrict__ slot) {
+    const float m = slot[0];
+    int e = 0;
+    if (m > 0.f) {
+        int ex;
+        frexpf(m, &ex);                 // m = f * 2^ex, f in [0.5, 1)
+        e = 14 - ex;                    // m * 2^e in [2^13, 2^14)
+    }
+    e = max(-100, min(100, e));
+    slot[0] = ldexpf(1.f, e);
+    slot[1] = ldexpf(1.f, -e);
+}
+
+// h[M][K] fp32 -> NT term planes [NT][M][kp16], kp16 = K rounded up to whole 16-wide steps (zero filled)
+template <class SP>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ h, int64_t ldh, int64_t M, int K,
-                                                           int kp16, __bf16* __restrict__ planes) {
+                                                           int kp16, typename SP::elem* __restrict__ planes) {
     const int cpr = kp16 / 8;                                  // 8-element chunks per row
     const int64_t total = M * cpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -729,44 +803,59 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         const int k = (int)(i - r * cpr) * 8;
         const bool live = k < K;                               // K % 8 == 0: whole chunk in or out
         const float* p = h + r * ldh + (live ? k : 0);
-        bf16x8 t0, t1, t2;
-        split3(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), live, t0, t1, t2);
-        __bf16* o = planes + r * kp16 + k;
-        *reinterpret_cast<bf16x8*>(o) = t0;
-        *reinterpret_cast<bf16x8*>(o + M * kp16) = t1;
-        *reinterpret_cast<bf16x8*>(o + 2 * M * kp16) = t2;
+        typename SP::vec t[SP::NT];
+        split_chunk<SP>(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), live, t);
+        typename SP::elem* o = planes + r * kp16 + k;
+#pragma unroll
+        for (int q = 0; q < SP::NT; ++q) *reinterpret_cast<typename SP::vec*>(o + q * M * kp16) = t[q];
     }
 }
 
+inline int split_terms(int dtype) { return dtype == NF_DTYPE_BF16X3 ? 3 : dtype == NF_DTYPE_F16X2 ? 2 : 0; }
 inline int kp16_of(int in) { return (in + XS - 1) / XS * XS; }
-inline size_t planes_bytes(int64_t B, int in) { return (size_t)3 * (size_t)B * kp16_of(in) * 2; }
+inline size_t planes_bytes(int64_t B, int in, int dtype) { return (size_t)split_terms(dtype) * (size_t)B * kp16_of(in) * 2; }
 
-inline size_t lds_bytes_x3(int fpt, int P) {
+inline size_t lds_bytes_split(int fpt, int P, int nt) {
     const size_t tile = sizeof(float) * (size_t)fpt * P * XLDT;
-    return (tile > (size_t)XSTAGE_BYTES ? tile : (size_t)XSTAGE_BYTES) + sizeof(float) * ((size_t)XM * fpt + (size_t)XM * (XT / 64));
+    const size_t stages = (size_t)2 * 2 * nt * (XA + XB);
+    return (tile > stages ? tile : stages) + sizeof(float) * ((size_t)XM * fpt + (size_t)XM * (XT / 64));
 }
 
-template <int KT, bool INV, bool PRE>
-int launch_one_x3(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+template <class SP, int KT, bool INV, bool PRE>
+int launch_one_split(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)made_rqs_x3_kernel<KT, INV, PRE>,
+        hipError_t e = hipFuncSetAttribute((const void*)made_rqs_split_kernel<SP, KT, INV, PRE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((made_rqs_x3_kernel<KT, INV, PRE>), dim3(grid), dim3(XT), lds, s, g);
+    hipLaunchKernelGGL((made_rqs_split_kernel<SP, KT, INV, PRE>), dim3(grid), dim3(XT), lds, s, g);
     return nf_launch_status();
 }
 
-template <bool INV, bool PRE>
-int launch_k_x3(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+template <class SP, bool INV, bool PRE>
+int launch_k_split(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
     switch (g.c.K) {
-        case 4: return launch_one_x3<4, INV, PRE>(g, grid, lds, s);
-        case 8: return launch_one_x3<8, INV, PRE>(g, grid, lds, s);
-        case 10: return launch_one_x3<10, INV, PRE>(g, grid, lds, s);
-        default: return launch_one_x3<0, INV, PRE>(g, grid, lds, s);
+        case 4: return launch_one_split<SP, 4, INV, PRE>(g, grid, lds, s);
+        case 8: return launch_one_split<SP, 8, INV, PRE>(g, grid, lds, s);
+        case 10: return launch_one_split<SP, 10, INV, PRE>(g, grid, lds, s);
+        default: return launch_one_split<SP, 0, INV, PRE>(g, grid, lds, s);
     }
+}
+
+// the split pre-pass (when the workspace has room for the planes and the launch covers the layer) + the kernel
+template <class SP>
+int run_split(FusedArgs& g, int grid, size_t lds, bool pre, const float* h, int64_t h_row_stride, int64_t B, int in,
+              int inverse, hipStream_t s) {
+    if (pre) {
+        const int64_t chunks = B * (g.hp_ld / 8);
+        const int sgrid = (int)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
+        hipLaunchKernelGGL(split_planes_kernel<SP>, dim3(sgrid), dim3(256), 0, s, h, h_row_stride, B, in, (int)g.hp_ld,
+                           (typename SP::elem*)g.hp);
+        return inverse ? launch_k_split<SP, true, true>(g, grid, lds, s) : launch_k_split<SP, false, true>(g, grid, lds, s);
+    }
+    return inverse ? launch_k_split<SP, true, false>(g, grid, lds, s) : launch_k_split<SP, false, false>(g, grid, lds, s);
 }
 
 inline int kpad_of(int in) { return (in + KPAD - 1) / KPAD * KPAD; }
@@ -818,7 +907,7 @@ extern "C" int nf_made_rqs_tiles(int features, int K, int tails) {
 extern "C" size_t nf_made_rqs_packed_bytes(int features, int in, int K, int tails, int dtype) {
     const int nt = nf_made_rqs_tiles(features, K, tails);
     if (nt == 0 || in <= 0) return 0;
-    return (size_t)nt * FN * kpad_of(in) * (dtype == NF_DTYPE_BF16 ? 2 : dtype == NF_DTYPE_BF16X3 ? 6 : 4);
+    return (size_t)nt * FN * kpad_of(in) * (dtype == NF_DTYPE_BF16 ? 2 : split_terms(dtype) ? 2 * split_terms(dtype) : 4);
 }
 
 extern "C" size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, int tails) {
@@ -828,8 +917,8 @@ extern "C" size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, in
 
 extern "C" size_t nf_made_rqs_workspace_bytes_dtype(int64_t B, int features, int in, int K, int tails, int dtype) {
     const size_t base = nf_made_rqs_workspace_bytes(B, features, K, tails);
-    if (base == 0 || dtype != NF_DTYPE_BF16X3 || in <= 0) return base;
-    return (base + 255) / 256 * 256 + planes_bytes(B, in);       // + the hidden state as three bf16 term planes
+    if (base == 0 || !split_terms(dtype) || in <= 0) return base;
+    return (base + 255) / 256 * 256 + planes_bytes(B, in, dtype);       // + the hidden state as three bf16 term planes
 }
 
 extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const float* bias, int features, int in,
@@ -838,16 +927,30 @@ extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const 
     if (!W || !packed || !bias_packed) return NF_ERR_NULL;     // ktab == NULL: keep the caller's table
     if (features <= 0 || in <= 0 || !fused_supported(K, tails) || !(logit_div > 0.0)) return NF_ERR_SHAPE;
     const float logit_fold = (float)(1.4426950408889634 / logit_div);
-    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && dtype != NF_DTYPE_BF16X3) return NF_ERR_DTYPE;
+    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && !split_terms(dtype)) return NF_ERR_DTYPE;
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
     const int fpt = fpt_of(P), nt = (features + fpt - 1) / fpt, out = features * P, kpad = kpad_of(in);
     const int64_t total = (int64_t)nt * FN * kpad;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == NF_DTYPE_BF16X3)
-        hipLaunchKernelGGL(pack_fused_x3_kernel, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
-                           3 * total, P, 2 * K, logit_fold, (__bf16*)packed, bias_packed);
-    else if (dtype == NF_DTYPE_F32)
+    if (dtype == NF_DTYPE_BF16X3) {
+        hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x3>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in,
+                           fpt * P, kpad, 3 * total, P, 2 * K, logit_fold, (const float*)nullptr, (__bf16*)packed,
+                           bias_packed);
+    } else if (dtype == NF_DTYPE_F16X2) {
+        if (!ktab) return NF_ERR_NULL;                 // the scale pair lives after the table
+        float* slot = (float*)(ktab + 2 * nt);
+        hipError_t me = hipMemsetAsync(slot, 0, 2 * sizeof(float), s);
+        if (me != hipSuccess) return (int)me;
+        const int64_t nw = (int64_t)out * in;
+        const int mgrid = (int)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
+        hipLaunchKernelGGL(maxabs_kernel, dim3(mgrid), dim3(256), 0, s, W, mask, nw, P, in, 2 * K, logit_fold,
+                           (unsigned*)slot);
+        hipLaunchKernelGGL(scale_slot_kernel, dim3(1), dim3(1), 0, s, slot);
+        hipLaunchKernelGGL(pack_fused_split_kernel<SplitF16x2>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in,
+                           fpt * P, kpad, 2 * total, P, 2 * K, logit_fold, (const float*)slot, (_Float16*)packed,
+                           bias_packed);
+    } else if (dtype == NF_DTYPE_F32)
         hipLaunchKernelGGL(pack_fused_kernel<float>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
                            total, P, 2 * K, logit_fold, (float*)packed, bias_packed);
     else
@@ -871,7 +974,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
                           int tile_count, int feat_limit, int reduce, void* stream) {
     if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
-    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && dtype != NF_DTYPE_BF16X3) return NF_ERR_DTYPE;
+    if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && !split_terms(dtype)) return NF_ERR_DTYPE;
     if (B == 0) return NF_OK;
     if (!h || !packed_w || !ktab || !bias_packed || !x || !y || !logabsdet || !workspace) return NF_ERR_NULL;
     if (h_row_stride < in || x_row_stride < row_width || y_row_stride < row_width) return NF_ERR_LAYOUT;
@@ -890,12 +993,13 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     g.n_tiles = tile_count;
     g.tn0 = tile_begin;
     g.feat_limit = feat_limit;
-    const bool x3 = dtype == NF_DTYPE_BF16X3;
+    const bool x3 = split_terms(dtype) != 0;
+    g.scale = (const float*)(ktab + 2 * all_tiles);
     g.m_tiles = x3 ? (B + XM - 1) / XM : (B + FM - 1) / FM;
     g.group_m = x3 ? 8 : 16;
     const int64_t grid = g.m_tiles * g.n_tiles;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    const size_t lds = x3 ? lds_bytes_x3(g.fpt, g.c.P) : lds_bytes(g.fpt, g.c.P);
+    const size_t lds = x3 ? lds_bytes_split(g.fpt, g.c.P, split_terms(dtype)) : lds_bytes(g.fpt, g.c.P);
     if (lds > 160 * 1024) return NF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     int rc = NF_OK;
@@ -904,18 +1008,13 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
             // whole-layer launches split the hidden state once (72 column tiles re-read it); the windowed
             // launches of the incremental inverse split it on the way into LDS instead
             const size_t part = (nf_made_rqs_workspace_bytes(B, features, K, tails) + 255) / 256 * 256;
-            const bool pre = tile_count == all_tiles && workspace_bytes >= part + planes_bytes(B, in);
+            const bool pre = tile_count == all_tiles && workspace_bytes >= part + planes_bytes(B, in, dtype);
             if (pre) {
                 g.hp = (const char*)workspace + part;
                 g.hp_ld = kp16_of(in);
-                const int64_t chunks = B * (g.hp_ld / 8);
-                const int sgrid = (int)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
-                hipLaunchKernelGGL(split_planes_kernel, dim3(sgrid), dim3(256), 0, s, h, h_row_stride, B, in,
-                                   (int)g.hp_ld, (__bf16*)g.hp);
-                rc = inverse ? launch_k_x3<true, true>(g, (int)grid, lds, s) : launch_k_x3<false, true>(g, (int)grid, lds, s);
-            } else {
-                rc = inverse ? launch_k_x3<true, false>(g, (int)grid, lds, s) : launch_k_x3<false, false>(g, (int)grid, lds, s);
             }
+            rc = dtype == NF_DTYPE_BF16X3 ? run_split<SplitBf16x3>(g, (int)grid, lds, pre, h, h_row_stride, B, in, inverse, s)
+                                          : run_split<SplitF16x2>(g, (int)grid, lds, pre, h, h_row_stride, B, in, inverse, s);
         }
         else if (dtype == NF_DTYPE_BF16)
             rc = inverse ? launch_k<true, true>(g, (int)grid, lds, s) : launch_k<true, false>(g, (int)grid, lds, s);

@@ -16,15 +16,19 @@ from torch.nn import functional as F, init
 
 from . import _lib
 
-_MATMUL_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_BF16X3}
+_MATMUL_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_BF16X3,
+                 'f16x2': _lib.NF_DTYPE_F16X2}
 # the hidden-layer GEMMs have no split-bf16 kernel yet: they stay on the fp32 matrix path in that mode
-_GEMM_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_F32}
+_GEMM_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_F32,
+               'f16x2': _lib.NF_DTYPE_F32}
 _default_matmul = 'f32'
 
 
 def set_matmul_dtype(name):
-    """'f32' (exact fp32 MFMA, the 1e-5 contract), 'bf16' (bf16 MFMA, the 2e-2 contract) or 'bf16x3' (the
-    fused final layer on six bf16 MFMAs per product of three-term split fp32 operands: the 1e-5 contract)."""
+    """'f32' (exact fp32 MFMA, the 1e-5 contract), 'bf16' (bf16 MFMA, the 2e-2 contract), 'bf16x3' (the
+    fused final layer on six bf16 MFMAs per product of three-term split fp32 operands: the 1e-5 contract) or
+    'f16x2' (three fp16 MFMAs per product of two-term split operands, weights power-of-two scaled: the 1e-5
+    contract while the hidden state stays below 1.3e5 in magnitude)."""
     global _default_matmul
     if name not in _MATMUL_DTYPE:
         raise ValueError('matmul dtype must be one of %s' % sorted(_MATMUL_DTYPE))

@@ -359,10 +359,12 @@ def test_bf16_mode_cfg3_within_2e_2(nf):
 # ------------------------------------------------------------------------------- split-bf16 mode
 @pytest.mark.parametrize('case', ['small', 'cfg3', 'roundtrip', 'incremental_inverse', 'coupling_linear',
                                   'coupling_notails', 'coupling_routes'])
-def test_bf16x3_mode_meets_the_fp32_contract(nf, case):
-    """'bf16x3': the fused final layer on six bf16 MFMAs per product of three-term split fp32 operands.
+@pytest.mark.parametrize('mode', ['bf16x3', 'f16x2'])
+def test_split_operand_modes_meet_the_fp32_contract(nf, mode, case):
+    """'bf16x3': the fused final layer on six bf16 MFMAs per product of three-term split fp32 operands;
+    'f16x2': three fp16 MFMAs per product of two-term split operands (weights power-of-two scaled).
     Same fixtures and the same 1e-5 bars as the exact-fp32 path (the tests above, re-run in that mode)."""
-    nf.set_matmul_dtype('bf16x3')
+    nf.set_matmul_dtype(mode)
     try:
         if case == 'small':
             test_rq_ar_small_golden(nf)
