@@ -35,7 +35,7 @@ extern "C" {
 #define NF_DTYPE_F32 0      /* v_mfma_f32_32x32x2_f32: exact fp32 products (1e-5 contract) */
 #define NF_DTYPE_BF16 1     /* v_mfma_f32_32x32x16_bf16 on bf16-rounded operands (2e-2 contract) */
 #define NF_DTYPE_F16X2 3    /* fp32 operands as two fp16 terms (weights scaled by a power of two chosen at pack time), three
-                             * fp16 MFMAs per product: same 1e-5 contract for |hidden state| < 1.3e5; fused entry points only.
+                             * fp16 MFMAs per product, hidden state scaled per launch likewise: same 1e-5 contract; fused entry points only.
                              * Its pack call needs ktab (the scale pair is kept in ktab[2*tiles .. 2*tiles+2)). */
 #define NF_DTYPE_BF16X3 2   /* fp32 operands as three bf16 terms, six bf16 MFMAs per product, fp32 accumulate: fp32-level
                              * accuracy (1e-5 contract) on the bf16 matrix pipe; nf_made_rqs_* / nf_coupling_rqs_fwd only */
@@ -119,8 +119,9 @@ int nf_made_rqs_tiles(int features, int K, int tails);
 size_t nf_made_rqs_packed_bytes(int features, int in, int K, int tails, int dtype);
 /* fp32 scratch for the per-tile logdet partial sums: tiles * B floats. */
 size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, int tails);
-/* Same for a given dtype: NF_DTYPE_BF16X3 adds room for the hidden state split into three bf16 planes
- * (3 * B * ceil16(in) * 2 bytes); with only nf_made_rqs_workspace_bytes the kernel splits on the fly. */
+/* Same for a given dtype: the split-operand dtypes add a 256-byte scale slot (required) and room for the
+ * hidden state split into term planes (terms * B * ceil16(in) * 2 bytes; without it, and in the windowed
+ * launches, the kernel splits on the fly).  nf_made_rqs_workspace_bytes + 512 covers the slot alone. */
 size_t nf_made_rqs_workspace_bytes_dtype(int64_t B, int features, int in, int K, int tails, int dtype);
 /* Packs the final layer W[features*P, in] (mask folded, rows regrouped to whole features per tile),
  * its K-range table (2*tiles + 2 int32: the last two hold NF_DTYPE_F16X2's scale pair) and its bias

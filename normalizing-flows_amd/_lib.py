@@ -277,6 +277,17 @@ class PackedFusedFinal:
                                                self.bias.data_ptr(), _stream()), 'nf_made_rqs_pack')
 
 
+def fused_workspace(pf, rows, device, planes=True):
+    """Scratch for made_rqs on `rows` samples: per-tile logdet partials, the split modes' scale slot and, with
+    `planes`, their pre-split hidden state (whole-layer launches)."""
+    lib = load()
+    if planes:
+        need = lib.nf_made_rqs_workspace_bytes_dtype(rows, pf.features, pf.inp, pf.K, pf.tails, pf.dtype)
+    else:
+        need = lib.nf_made_rqs_workspace_bytes(rows, pf.features, pf.K, pf.tails) + 512
+    return torch.empty(max(1, (need + 3) // 4), dtype=torch.float32, device=device)
+
+
 def made_rqs_supported(num_bins, tails, hidden):
     return (tails in (None, 'linear') and hidden % 8 == 0
             and load().nf_made_rqs_supported(int(num_bins), 1 if tails == 'linear' else 0) == 1)
@@ -311,9 +322,7 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
         accumulate = False
     bins = torch.empty((B, pf.features), dtype=torch.int32, device=x.device) if want_bins else None
     if workspace is None:
-        need = lib.nf_made_rqs_workspace_bytes_dtype(B, pf.features, pf.inp, pf.K, pf.tails,
-                                                      pf.dtype if tiles is None else NF_DTYPE_F32)
-        workspace = torch.empty(max(1, (need + 3) // 4), dtype=torch.float32, device=x.device)
+        workspace = fused_workspace(pf, B, x.device, planes=tiles is None)
     ws = workspace
     tb, tc = (0, pf.tiles) if tiles is None else tiles
     fl = pf.features if feat_limit is None else feat_limit

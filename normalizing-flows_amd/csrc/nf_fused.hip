@@ -56,6 +56,7 @@ struct FusedArgs {
     int32_t* bins;           // nullable [M, D]
     const int32_t* feat_index;   // nullable [D]: column of x / y that holds feature f (coupling layers)
     const float* scale;      // f16x2: {2^e, 2^-e} weight scale pair written at pack time (after the K-range table)
+    const float* hscale;     // f16x2: the same pair for this launch's hidden state (in the workspace)
     const void* hp;          // split-operand full launches: h pre-split into three bf16 term planes [3][M][hp_ld]
     int64_t hp_ld;
     int64_t M;
@@ -443,8 +444,9 @@ __global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict
 // Split-fp16 ("f16x2") flavour of the same kernel: two fp16 terms a = a0 + a1 (11 + 11 mantissa bits),
 // three products a0b0, a0b1, a1b0 on v_mfma_f32_32x32x16_f16; the dropped a1b1 is 2^-22 relative, below
 // the fp32 accumulation error of a 512-term sum.  fp16 has 5 exponent bits, so the weights are scaled by
-// a power of two chosen at pack time (largest magnitude just under 2^14; undone exactly in the epilogue)
-// and the hidden state is taken as is: exact to 2^-25 absolute for |h| < 131008 (beyond: saturates).
+// a power of two chosen at pack time and the hidden state by one found per launch (largest finite magnitude
+// just under 2^14 each; both undone exactly in the epilogue), so nothing finite overflows and an element
+// keeps 22 bits unless it is 2^-14 times smaller than the largest one (then 2^-39 of that one, absolute).
 // Half the matrix work and 2/3 of the operand traffic of bf16x3 - this kernel is power-limited, not
 // issue-limited (the clock drops to ~1.7 GHz under it), so energy per product is what buys time.
 constexpr int XM = 128, XT = 256, XS = 16;     // samples per workgroup, threads, K elements per step
@@ -484,9 +486,7 @@ struct SplitF16x2 {
     typedef _Float16 elem;
     typedef f16x8 vec;
     static __device__ __forceinline__ void split1(float a, elem (&t)[NT]) {
-        float c = fminf(fmaxf(a, -65504.f), 65504.f);
-        if (a != a) c = a;                         // NaN stays NaN
-        t[0] = (_Float16)c;
+        t[0] = (_Float16)a;                       // operands arrive scaled below 2^14: no finite overflow
         t[1] = (_Float16)(a - (float)t[0]);
     }
     static __device__ __forceinline__ void fma_tile(f32x16& acc, const vec (&a)[NT], const vec (&b)[NT]) {
@@ -497,12 +497,13 @@ struct SplitF16x2 {
 };
 
 template <class SP>
-__device__ __forceinline__ void split_chunk(const float4& lo, const float4& hi, bool live, typename SP::vec (&t)[SP::NT]) {
+__device__ __forceinline__ void split_chunk(const float4& lo, const float4& hi, bool live, float scale,
+                                            typename SP::vec (&t)[SP::NT]) {
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         typename SP::elem e[SP::NT];
-        SP::split1(live ? v[j] : 0.f, e);
+        SP::split1(live ? (SP::SCALED ? v[j] * scale : v[j]) : 0.f, e);
 #pragma unroll
         for (int p = 0; p < SP::NT; ++p) t[p][j] = e[p];
     }
@@ -544,10 +545,11 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
     const int kt_begin = g.ktab[2 * tn];
     const int kt_end = min(g.ktab[2 * tn + 1], (g.K + XS - 1) / XS);
 
+    const float hs = SP::SCALED ? g.hscale[0] : 1.f;    // power-of-two scale of this launch's hidden state
     f32x16 acc[4][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const float bv = g.bias[tn * FN + wc * 64 + j * 32 + (lane & 31)] * (SP::SCALED ? g.scale[0] : 1.f);
+        const float bv = g.bias[tn * FN + wc * 64 + j * 32 + (lane & 31)] * (SP::SCALED ? g.scale[0] * hs : 1.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
         if (PRE) {                                                                                    \
             _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) t_[p_] = rp[p_];                        \
         } else {                                                                                      \
-            split_chunk<SP>(ra0, ra1, (kt_) * XS + ahalf * 8 < g.K, t_);                              \
+            split_chunk<SP>(ra0, ra1, (kt_) * XS + ahalf * 8 < g.K, hs, t_);                            \
         }                                                                                             \
         _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) *reinterpret_cast<vec*>(sa_ + p_ * XA) = t_[p_]; \
         _Pragma("unroll") for (int q_ = 0; q_ < 2 * NT; ++q_)                                         \
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
 #undef X3_LOAD_PIECE
 
     // ---- epilogue: two passes of 64 samples (row blocks 2*half, 2*half + 1 of the accumulators) ------
-    const float oscale = SP::SCALED ? g.scale[1] : 1.f;
+    const float oscale = SP::SCALED ? g.scale[1] * g.hscale[1] : 1.f;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
@@ -792,10 +794,29 @@ __global__ void scale_slot_kernel(float* __restrict__ slot) {
     slot[1] = ldexpf(1.f, -e);
 }
 
+// largest finite |h| of h[M][K] into slot[0] (bit pattern, see above)
+__global__ __launch_bounds__(256) void maxabs_rows_kernel(const float* __restrict__ h, int64_t ldh, int64_t M, int K,
+                                                          unsigned* __restrict__ slot) {
+    const int cpr = K / 4;
+    const int64_t total = M * cpr;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cpr;
+        const float4 v = *reinterpret_cast<const float4*>(h + r * ldh + (i - r * cpr) * 4);
+        const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));   // fmaxf drops NaN
+        m = fmaxf(m, a < INFINITY ? a : 0.f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+
 // h[M][K] fp32 -> NT term planes [NT][M][kp16], kp16 = K rounded up to whole 16-wide steps (zero filled)
 template <class SP>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ h, int64_t ldh, int64_t M, int K,
-                                                           int kp16, typename SP::elem* __restrict__ planes) {
+                                                           int kp16, const float* __restrict__ hscale,
+                                                           typename SP::elem* __restrict__ planes) {
+    const float hs = SP::SCALED ? hscale[0] : 1.f;
     const int cpr = kp16 / 8;                                  // 8-element chunks per row
     const int64_t total = M * cpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -804,7 +825,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         const bool live = k < K;                               // K % 8 == 0: whole chunk in or out
         const float* p = h + r * ldh + (live ? k : 0);
         typename SP::vec t[SP::NT];
-        split_chunk<SP>(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), live, t);
+        split_chunk<SP>(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), live, hs, t);
         typename SP::elem* o = planes + r * kp16 + k;
 #pragma unroll
         for (int q = 0; q < SP::NT; ++q) *reinterpret_cast<typename SP::vec*>(o + q * M * kp16) = t[q];
@@ -848,11 +869,20 @@ int launch_k_split(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
 template <class SP>
 int run_split(FusedArgs& g, int grid, size_t lds, bool pre, const float* h, int64_t h_row_stride, int64_t B, int in,
               int inverse, hipStream_t s) {
+    if (SP::SCALED) {
+        float* slot = const_cast<float*>(g.hscale);
+        hipError_t me = hipMemsetAsync(slot, 0, 2 * sizeof(float), s);
+        if (me != hipSuccess) return (int)me;
+        const int64_t q4 = B * (in / 4);
+        const int mgrid = (int)((q4 + 255) / 256 < 4096 ? (q4 + 255) / 256 : 4096);
+        hipLaunchKernelGGL(maxabs_rows_kernel, dim3(mgrid), dim3(256), 0, s, h, h_row_stride, B, in, (unsigned*)slot);
+        hipLaunchKernelGGL(scale_slot_kernel, dim3(1), dim3(1), 0, s, slot);
+    }
     if (pre) {
         const int64_t chunks = B * (g.hp_ld / 8);
         const int sgrid = (int)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
         hipLaunchKernelGGL(split_planes_kernel<SP>, dim3(sgrid), dim3(256), 0, s, h, h_row_stride, B, in, (int)g.hp_ld,
-                           (typename SP::elem*)g.hp);
+                           g.hscale, (typename SP::elem*)g.hp);
         return inverse ? launch_k_split<SP, true, true>(g, grid, lds, s) : launch_k_split<SP, false, true>(g, grid, lds, s);
     }
     return inverse ? launch_k_split<SP, true, false>(g, grid, lds, s) : launch_k_split<SP, false, false>(g, grid, lds, s);
@@ -918,7 +948,7 @@ extern "C" size_t nf_made_rqs_workspace_bytes(int64_t B, int features, int K, in
 extern "C" size_t nf_made_rqs_workspace_bytes_dtype(int64_t B, int features, int in, int K, int tails, int dtype) {
     const size_t base = nf_made_rqs_workspace_bytes(B, features, K, tails);
     if (base == 0 || !split_terms(dtype) || in <= 0) return base;
-    return (base + 255) / 256 * 256 + planes_bytes(B, in, dtype);       // + the hidden state as three bf16 term planes
+    return (base + 255) / 256 * 256 + 256 + planes_bytes(B, in, dtype);   // + scale slot + term planes       // + the hidden state as three bf16 term planes
 }
 
 extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const float* bias, int features, int in,
@@ -985,7 +1015,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     FusedArgs g;
     g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
-    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hscale = nullptr;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
@@ -1008,9 +1038,11 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
             // whole-layer launches split the hidden state once (72 column tiles re-read it); the windowed
             // launches of the incremental inverse split it on the way into LDS instead
             const size_t part = (nf_made_rqs_workspace_bytes(B, features, K, tails) + 255) / 256 * 256;
-            const bool pre = tile_count == all_tiles && workspace_bytes >= part + planes_bytes(B, in, dtype);
+            if (workspace_bytes < part + 256) return NF_ERR_SCRATCH;      // the hidden-state scale slot
+            g.hscale = (const float*)((const char*)workspace + part);
+            const bool pre = tile_count == all_tiles && workspace_bytes >= part + 256 + planes_bytes(B, in, dtype);
             if (pre) {
-                g.hp = (const char*)workspace + part;
+                g.hp = (const char*)workspace + part + 256;
                 g.hp_ld = kp16_of(in);
             }
             rc = dtype == NF_DTYPE_BF16X3 ? run_split<SplitBf16x3>(g, (int)grid, lds, pre, h, h_row_stride, B, in, inverse, s)

@@ -252,7 +252,7 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
             z, out = inputs[s:e], outputs[s:e]
             bufs = {n: torch.empty((e - s, H), dtype=inputs.dtype, device=inputs.device) for n in names}
             bufs['x'] = out
-            ws = torch.empty(pf.tiles * (e - s), dtype=torch.float32, device=inputs.device)
+            ws = _lib.fused_workspace(pf, e - s, inputs.device, planes=False)
             for gi, (a, b) in enumerate(groups):
                 hidden = net.run_hidden_program(bufs, degree=None if gi == 0 else a)
                 t0, t1 = a // fpt, b // fpt

@@ -385,6 +385,41 @@ def test_split_operand_modes_meet_the_fp32_contract(nf, mode, case):
         nf.set_matmul_dtype('f32')
 
 
+@pytest.mark.parametrize('mode', ['bf16x3', 'f16x2'])
+def test_split_operand_modes_with_extreme_operand_ranges(nf, mode):
+    """Hidden state ~1e5 against final-layer weights ~1e-7 (and the reverse): outside fp16's range as they
+    stand; the power-of-two scales of the f16x2 flavour must make the result match the exact-fp32 mode."""
+    torch.manual_seed(9)
+    D, H, K = 40, 64, 8
+    x = torch.randn(200, D, device='cuda')
+    for up in (1e5, 1e-5):
+        t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, num_bins=K, tails='linear',
+                                                                       tail_bound=3.).cuda().eval()
+        with torch.no_grad():
+            net = t.autoregressive_net
+            net.initial_layer.weight.mul_(up)
+            net.initial_layer.bias.mul_(up)
+            for blk in net.blocks:                      # keep the residual stream at the scale of the first layer
+                blk.linear_layers[1].weight.mul_(up)
+                blk.linear_layers[1].bias.mul_(up)
+                blk.linear_layers[0].weight.mul_(1.0 / up)
+            net.final_layer.weight.mul_(1.0 / up)
+            sd = {k: v.detach().cpu() for k, v in t.state_dict().items()}
+            sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+            y64, ld64 = O.rq_autoregressive_forward(sd64, x.cpu().double(), K, 3.0)
+            y32, ld32 = O.rq_autoregressive_forward(sd, x.cpu(), K, 3.0)
+            nf.set_matmul_dtype(mode)
+            try:
+                y1, ld1 = t(x)
+                xi, ldi = t.inverse(y1)
+            finally:
+                nf.set_matmul_dtype('f32')
+        assert torch.isfinite(y1).all() and (y64 - x.cpu().double()).abs().max().item() > 1e-3   # the layer does something
+        assert_close(y1, y64, y32)
+        assert_close(ld1, ld64, ld32)
+        assert (xi - x).abs().max().item() < 1e-4
+
+
 # ------------------------------------------------------------------------------- affine / coupling
 def test_affine_ar_golden(nf):
     fx = load_golden('affine_ar')
