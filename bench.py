@@ -10,10 +10,18 @@ one step = log_prob of one batch of 262144 synthetic N(0,I) samples already resi
 GPU (weak scaling: the batch is sharded, config 4).  Weights: nn.Linear default init under
 torch.manual_seed(0) (identical on every rank); data: torch.Generator(1234 + rank).
 
+Matrix arithmetic (--dtype): 'f16x2' (default) carries every fp32 operand of the dominant layer as two
+fp16 terms (power-of-two scaled) and forms each product from three fp16 MFMAs with fp32 accumulation -
+fp32-level results (the 1e-5 parity bar, checked against the oracle in this run) on the fp16 matrix
+pipe; 'bf16x3' = three bf16 terms, six MFMAs; 'f32' = v_mfma_f32_32x32x2_f32 (exact fp32 products);
+'bf16' = operands rounded to bf16 (the 2e-2 contract).  The other modes are timed as secondary figures.
+
 One JSON line on rank 0, with
-  roofline     - the dominant kernel (final MADE layer, masked fp32-MFMA GEMM): algorithmic FLOP per
+  roofline     - the dominant kernel (final MADE layer fused with the spline): algorithmic FLOP per
                  launch (2 x unmasked weights x rows) / its average launch time, measured with HIP
-                 events on the launch stream inside the timed steps, against the fp32 matrix peak;
+                 events on the launch stream inside the timed steps, against the dense matrix peak of
+                 the pipe it runs on (fp16/bf16 2.5 PF, fp32 157.3 TF); the split modes execute 3 (6)
+                 MFMA flop per algorithmic flop, reported beside it;
   cpu_baseline - oracle/nf_oracle.py (the reference's ATen op sequence) on this box's host cores, on a
                  bounded sample, also used to check the GPU log_prob of those rows.
 """
@@ -33,9 +41,14 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 # HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE doubled as the
-# microarch guide prescribes for gfx950, + WRITE_SIZE), collected separately: profiles/r01_h_f32_fused64_pmc.txt.
+# microarch guide prescribes for gfx950, + WRITE_SIZE), collected separately: profiles/r01_i_f16x2_pmc.txt
+# (f32 mode: profiles/r01_h_f32_fused64_pmc.txt).
 # Keyed by (dtype, fused kernel?, rows per launch); other shapes report null.
-TRAFFIC_BYTES_PER_LAUNCH = {('f32', True, 131072): 5.72e9}
+TRAFFIC_BYTES_PER_LAUNCH = {('f32', True, 131072): 5.72e9, ('f16x2', True, 131072): 5.68e9}
+DTYPE_LABEL = {'f32': 'f32', 'bf16': 'bf16-mfma/f32-accumulate',
+               'bf16x3': 'f32 as 3 bf16 terms (6 bf16 MFMA per product, f32 accumulate)',
+               'f16x2': 'f32 as 2 fp16 terms (3 fp16 MFMA per product, f32 accumulate)'}
+MFMA_PER_PRODUCT = {'f32': 1, 'bf16': 1, 'bf16x3': 6, 'f16x2': 3}
 
 
 def build_flow(nf):
@@ -69,10 +82,11 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=262144, help='samples per GPU per step')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'bf16x3', 'f16x2'], help='MADE matrix-core input type')
+    ap.add_argument('--dtype', default='f16x2', choices=['f32', 'bf16', 'bf16x3', 'f16x2'],
+                    help='matrix arithmetic of the dominant layer (see the module docstring)')
     ap.add_argument('--cpu-sample', type=int, default=2048)
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--no-bf16', action='store_true', help='skip the secondary bf16-MFMA measurement')
+    ap.add_argument('--no-bf16', action='store_true', help='skip the secondary measurements in the other modes')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -136,7 +150,7 @@ def main():
             'value': total / elapsed, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.dtype == 'f32' else 'bf16-mfma/f32-accumulate',
+            'dtype': DTYPE_LABEL[args.dtype],
             'data': 'synthetic N(0,I) samples, default-init weights (seed 0)',
             'config': {'workload': 'cfg3: 5x RQ-spline MAF layer D=784 H=512 K=8 tails=linear T=3, log_prob',
                        'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'batch-sharded x%d' % world,
@@ -154,10 +168,13 @@ def main():
             flop = 2.0 * nnz * rows
             peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
             ach = flop / (ms * 1e-3) / 1e12
+            mpp = MFMA_PER_PRODUCT[args.dtype]
             out['roofline'] = {'bound': 'mfma',
                                'kernel': ('made_rqs_kernel<%s> (final layer 512->18032 fused with the spline)' if fused
                                           else 'masked_linear_%s_kernel (final layer 512->18032)') % args.dtype,
                                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                               'mfma_flop_per_algorithmic_flop': mpp, 'executed_tflops': ach * mpp,
+                               'executed_frac': ach * mpp / peak, 'achieved_over_fp32_matrix_peak': ach / PEAK_F32_MFMA_TFLOPS,
                                'traffic': TRAFFIC_BYTES_PER_LAUNCH.get((args.dtype, fused, rows)), 'launches': n, 'avg_launch_ms': ms, 'rows_per_launch': rows,
                                'algorithmic_flop_per_launch': flop,
                                'dense_equiv_tflops': 2.0 * final.out_features * final.in_features * rows / (ms * 1e-3) / 1e12}
@@ -170,22 +187,26 @@ def main():
                                     'unit': 'GB/s', 'frac': byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                     'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': byts}
         out['kernel_ms'] = {'%s_%dx%d_rows%d' % (k[0], k[1], k[2], k[3]): round(v[1], 4) for k, v in kern.items()}
-        if args.dtype == 'f32' and not args.no_bf16:
-            # secondary figure: the same step with the MADE layers on bf16 MFMA (north_star's 2e-2 contract)
-            nf.set_matmul_dtype('bf16')
-            with torch.no_grad():
-                lp16 = flow.log_prob(x)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                lp16, _ = step()
-            torch.cuda.synchronize()
-            dt16 = time.perf_counter() - t1
-            nf.set_matmul_dtype('f32')
-            out['bf16_mode'] = {'value': B * args.steps / dt16, 'unit': 'samples/s (this rank)',
-                                'ms_per_step': 1e3 * dt16 / args.steps, 'dtype': 'bf16-mfma/f32-accumulate',
-                                'max_rel_diff_vs_f32_log_prob':
-                                    ((lp16 - logp).abs() / logp.abs().clamp_min(1.0)).max().item()}
+        if not args.no_bf16:
+            # secondary figures: the same step in the other matrix modes (this rank's shard)
+            out['other_modes'] = {}
+            for mode in ('f32', 'bf16x3', 'f16x2', 'bf16'):
+                if mode == args.dtype:
+                    continue
+                nf.set_matmul_dtype(mode)
+                with torch.no_grad():
+                    lpm = flow.log_prob(x)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    lpm, _ = step()
+                torch.cuda.synchronize()
+                dtm = time.perf_counter() - t1
+                out['other_modes'][mode] = {'value': B * args.steps / dtm, 'unit': 'samples/s (this rank)',
+                                            'ms_per_step': 1e3 * dtm / args.steps, 'dtype': DTYPE_LABEL[mode],
+                                            'max_rel_diff_vs_headline_log_prob':
+                                                ((lpm - logp).abs() / logp.abs().clamp_min(1.0)).max().item()}
+            nf.set_matmul_dtype(args.dtype)
         f32_tf, bf16_tf, copy_gbs = nf._lib.measure_device_peaks()
         out['measured_device_peaks'] = {'mfma_f32_tflops': f32_tf, 'mfma_bf16_tflops': bf16_tf, 'copy_gbs': copy_gbs,
                                         'note': 'back-to-back MFMA issue loop / 1 GiB float4 copy on this device; the '
