@@ -166,6 +166,32 @@ int nf_coupling_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed
                         int in, int features, int K, int tails, double tail_bound, double min_bin_width,
                         double min_bin_height, double min_derivative, int inverse, int dtype, void* stream);
 
+/* nf_made_rqs_fwd with `h_max`: the slot a split-operand producer (nf_masked_linear_split_fwd's y_max) left
+ * max |h| in, which saves the kernel's own pass over h.  NULL = nf_made_rqs_fwd. */
+int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h_max, const void* packed_w,
+                         const int32_t* ktab, const float* bias_packed, const float* x, int64_t x_row_stride,
+                         float* y, int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                         float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
+                         int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                         double min_derivative, int inverse, int dtype, void* stream);
+
+/* ---- hidden-layer GEMMs on split operands (NF_DTYPE_F16X2 / NF_DTYPE_BF16X3; replaces made.py:150-152 like
+ *      nf_masked_linear_fwd, same fp32 contract, fp16 / bf16 matrix pipe) --------------------------------- */
+
+/* 256-column output tiles; packed bytes; pack (ktab: 2*tiles + 2 int32, bias_packed: tiles*256 floats). */
+int nf_linear_split_tiles(int out);
+size_t nf_linear_split_packed_bytes(int out, int in, int dtype);
+int nf_linear_split_pack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
+                         void* packed, int32_t* ktab, float* bias_packed, void* stream);
+/* slot <- bit pattern of the largest finite |x[b, c]| (cols % 4 == 0, 16-byte aligned rows). */
+int nf_maxabs(const float* x, int64_t x_row_stride, int64_t B, int cols, uint32_t* slot, void* stream);
+/* y = [relu](x) @ (W*mask)^T + bias (+ residual) [relu].  x_max: slot holding max |x| (nf_maxabs, or the y_max of
+ * the launch that produced x; required for NF_DTYPE_F16X2); y_max (nullable) receives max |y|.  in % 8 == 0. */
+int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, const uint32_t* x_max, const void* packed_w,
+                               const int32_t* ktab, const float* bias_packed, const float* residual,
+                               int64_t res_row_stride, float* y, int64_t y_row_stride, uint32_t* y_max, int64_t B,
+                               int in, int out, int relu_in, int relu_out, int dtype, void* stream);
+
 /* ---- coupling conditioner: the ResidualNet's hidden stack in one launch ------------------------------
  *      (replaces resnet.py:96-98 `initial_layer` + `blocks` and the `inputs[:, identity_features]` gather of
  *       transforms.py:88; BatchNorm in eval mode folded to scale/shift; no context, ReLU only) --------- */

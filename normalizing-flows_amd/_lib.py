@@ -66,6 +66,20 @@ _SIGNATURES = {
                                        _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int,
                                        _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
                                        _c.c_double, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_made_rqs_fwd_hmax': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                        _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int,
+                                        _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                        _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
+                                        _c.c_int, _c.c_void_p]),
+    'nf_linear_split_tiles': (_c.c_int, [_c.c_int]),
+    'nf_linear_split_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    'nf_linear_split_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                        _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'nf_maxabs': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    'nf_masked_linear_split_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                              _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                              _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                              _c.c_int, _c.c_void_p]),
     'nf_resnet_blob_floats': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_resnet_hidden_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p,
                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
@@ -177,6 +191,73 @@ class PackedLinear:
         with torch.cuda.device(w.device):
             _check(lib.nf_made_pack(w.data_ptr(), _ptr(m), self.out, self.inp, dtype, self.packed.data_ptr(),
                                     self.ktab.data_ptr() if fresh else None, _stream()), 'nf_made_pack')
+
+
+class PackedLinearSplit:
+    """Device buffers of nf_linear_split_pack: one [out,in] layer as fp16 / bf16 term planes in 256-row tiles."""
+    __slots__ = ('out', 'inp', 'dtype', 'packed', 'ktab', 'bias', 'tiles')
+
+    def __init__(self, weight, mask, bias, dtype):
+        lib = load()
+        w = _dev(weight.detach().contiguous(), 'weight')
+        m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
+        b = None if bias is None else _dev(bias.detach().contiguous(), 'bias')
+        self.out, self.inp, self.dtype = int(w.shape[0]), int(w.shape[1]), dtype
+        self.tiles = lib.nf_linear_split_tiles(self.out)
+        self.packed = torch.empty(lib.nf_linear_split_packed_bytes(self.out, self.inp, dtype), dtype=torch.uint8,
+                                  device=w.device)
+        self.ktab = torch.zeros(2 * self.tiles + 2, dtype=torch.int32, device=w.device)
+        self.bias = torch.empty(256 * self.tiles, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _check(lib.nf_linear_split_pack(w.data_ptr(), _ptr(m), _ptr(b), self.out, self.inp, dtype,
+                                            self.packed.data_ptr(), self.ktab.data_ptr(), self.bias.data_ptr(),
+                                            _stream()), 'nf_linear_split_pack')
+
+
+def split_gemm_supported(x, in_features):
+    """Shapes the split-operand hidden-layer kernel takes: 16-byte rows, in_features a multiple of 8."""
+    return (in_features % 8 == 0 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0)
+
+
+def maxabs(x):
+    """int32[1] slot holding the bit pattern of the largest finite |x| (operand scale of the f16x2 kernels)."""
+    lib = load()
+    _dev(x, 'x')
+    xp, xs = _rows(x, 'x')
+    slot = torch.empty(1, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.nf_maxabs(xp, xs, x.shape[0], x.shape[1], slot.data_ptr(), _stream()), 'nf_maxabs')
+    return slot
+
+
+def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, out=None):
+    """Split-operand hidden-layer GEMM.  The result carries `_nf_max` (slot with max |out|) so that a following
+    split-operand launch needs no pass over it; x's own slot is used when present, else computed here."""
+    lib = load()
+    _dev(x, 'x')
+    xp, xs = _rows(x, 'x')
+    B = x.shape[0]
+    if x.shape[1] != pls.inp:
+        raise ValueError('Expected %d input features, got %d' % (pls.inp, x.shape[1]))
+    if out is None:
+        out = torch.empty((B, pls.out), dtype=torch.float32, device=x.device)
+    yp, ys = _rows(out, 'out')
+    rp, rs = (None, 0) if residual is None else _rows(_dev(residual, 'residual'), 'residual')
+    x_max = getattr(x, '_nf_max', None)
+    if x_max is None and pls.dtype == NF_DTYPE_F16X2:
+        x_max = maxabs(x)
+    y_max = torch.empty(1, dtype=torch.int32, device=x.device)
+
+    def launch():
+        return lib.nf_masked_linear_split_fwd(xp, xs, _ptr(x_max), pls.packed.data_ptr(), pls.ktab.data_ptr(),
+                                              pls.bias.data_ptr(), rp, rs, yp, ys, y_max.data_ptr(), B, pls.inp, pls.out,
+                                              int(relu_in), int(relu_out), pls.dtype, _stream())
+    with torch.cuda.device(x.device):
+        code = launch() if _timer is None else _timer.record(('masked_linear', pls.inp, pls.out, B), launch)
+        _check(code, 'nf_masked_linear_split_fwd')
+    out._nf_max = y_max
+    return out
 
 
 class PackedLinearT:
@@ -326,6 +407,9 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
     ws = workspace
     tb, tc = (0, pf.tiles) if tiles is None else tiles
     fl = pf.features if feat_limit is None else feat_limit
+    # a split-operand producer left max |h| beside the tensor: whole-layer launches can skip their own pass
+    h_max = getattr(h, '_nf_max', None) if (tiles is None and feat_limit is None and feat_index is None
+                                            and pf.dtype == NF_DTYPE_F16X2) else None
 
     def launch():
         if feat_index is not None:
@@ -335,6 +419,12 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
                                            pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
                                            float(min_bin_height), float(min_derivative), int(inverse), pf.dtype,
                                            _stream())
+        if h_max is not None:
+            return lib.nf_made_rqs_fwd_hmax(hp, hs, h_max.data_ptr(), pf.packed.data_ptr(), pf.ktab.data_ptr(),
+                                            pf.bias.data_ptr(), xp, xs, yp, ys, logabsdet.data_ptr(), int(accumulate),
+                                            _ptr(bins), ws.data_ptr(), ws.numel() * 4, B, pf.inp, pf.features, pf.K,
+                                            pf.tails, float(tail_bound), float(min_bin_width), float(min_bin_height),
+                                            float(min_derivative), int(inverse), pf.dtype, _stream())
         return lib.nf_made_rqs_fwd_tiles(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs,
                                          yp, ys, logabsdet.data_ptr(), int(accumulate), _ptr(bins), ws.data_ptr(),
                                          ws.numel() * 4, B, pf.inp, pf.features, pf.K, pf.tails, float(tail_bound),
@@ -389,6 +479,8 @@ def masked_linear(x, pl, residual=None, in_scale=None, in_shift=None, relu_in=Fa
     if out is None:
         out = torch.empty((B, pl.out), dtype=torch.float32, device=x.device)
     yp, ys = _rows(out, 'out')
+    if getattr(out, '_nf_max', None) is not None:
+        out._nf_max = None              # a split-operand launch's max |out| no longer describes this buffer
     rp, rs = (None, 0) if residual is None else _rows(_dev(residual, 'residual'), 'residual')
     tb, tc = (0, (pl.out + 127) // 128) if tiles is None else tiles
 

@@ -55,8 +55,12 @@ struct FusedArgs {
     float* partial;          // [n_tiles][M]
     int32_t* bins;           // nullable [M, D]
     const int32_t* feat_index;   // nullable [D]: column of x / y that holds feature f (coupling layers)
-    const float* scale;      // f16x2: {2^e, 2^-e} weight scale pair written at pack time (after the K-range table)
-    const float* hscale;     // f16x2: the same pair for this launch's hidden state (in the workspace)
+    const unsigned* wmax;    // f16x2: bit pattern of max |packed weight| before scaling (kept after the K-range table)
+    const unsigned* hmax;    // f16x2: bit pattern of max |A operand| of this launch (workspace slot or the producer's)
+    const float* residual;   // split hidden-layer GEMM: nullable [M, N] added to the output
+    int64_t ldr;
+    int N, relu_out;         // split hidden-layer GEMM: output columns, ReLU on the output
+    unsigned* out_max;       // split hidden-layer GEMM: nullable slot that receives max |output| (next layer's hmax)
     const void* hp;          // split-operand full launches: h pre-split into three bf16 term planes [3][M][hp_ld]
     int64_t hp_ld;
     int64_t M;
@@ -496,60 +500,50 @@ struct SplitF16x2 {
     }
 };
 
-template <class SP>
+// s = 2^e with m * 2^e in [2^13, 2^14) for the float whose bit pattern is `bits` (0 / denormal: s = 1); inv = 2^-e
+__device__ __forceinline__ void pow2_pair(unsigned bits, float& s, float& inv) {
+    const int ex = (int)((bits >> 23) & 0xff) - 126;          // m = f * 2^ex, f in [0.5, 1)
+    int e = ((bits >> 23) & 0xff) == 0 ? 0 : 14 - ex;
+    e = max(-100, min(100, e));
+    s = __uint_as_float((unsigned)(e + 127) << 23);
+    inv = __uint_as_float((unsigned)(127 - e) << 23);
+}
+
+template <class SP, bool RELU = false>
 __device__ __forceinline__ void split_chunk(const float4& lo, const float4& hi, bool live, float scale,
                                             typename SP::vec (&t)[SP::NT]) {
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         typename SP::elem e[SP::NT];
-        SP::split1(live ? (SP::SCALED ? v[j] * scale : v[j]) : 0.f, e);
+        float a = live ? v[j] : 0.f;
+        if (RELU) a = fmaxf(a, 0.f);
+        SP::split1(SP::SCALED ? a * scale : a, e);
 #pragma unroll
         for (int p = 0; p < SP::NT; ++p) t[p][j] = e[p];
     }
 }
 
-template <class SP, int KT, bool INV, bool PRE>
-__global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g) {
+// The K loop shared by the split-operand kernels: acc (+)= A[m0.., :] @ Wpacked[tile tn]^T over the tile's live
+// 16-wide K steps, accumulators started at bias * bscale.  A comes from g.h (fp32, split on the fly with scale
+// hs, ReLU first when RELU) or, PRE, from the term planes g.hp.
+template <class SP, bool PRE, bool RELU>
+__device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int64_t m0, int tn, int tid, float bscale,
+                                             float hs, f32x16 (&acc)[4][2]) {
     constexpr int NT = SP::NT;
     constexpr int XSTAGE = NT * (XA + XB);             // elements per stage
-    constexpr int XSTAGE_BYTES = 2 * 2 * XSTAGE;       // both stages
     constexpr int XUNITS = NT * FN * XS / 8;           // 16-byte units of one packed weight step
     constexpr int NP = 3 * NT;                         // load pieces per step: NT of A, 2 NT of B
     typedef typename SP::vec vec;
     typedef typename SP::elem elem;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int fpt = g.fpt, P = g.c.P;
-    const int ncol = fpt * P;
     elem* stage0 = (elem*)lds;                       // stage s at stage0 + s * XSTAGE: A planes, then B planes
-    float* tile = (float*)lds;                       // epilogue: [ncol][XLDT], aliases the staging planes
-    float* xs = (float*)(lds + max(XSTAGE_BYTES, ncol * XLDT * 4));   // [128][fpt]
-    float* ldp = xs + XM * fpt;                      // [4 waves][128]
-
-    int64_t tm;
-    int tn;
-    tile_of_block(g, tm, tn);
-    const int64_t m0 = tm * XM;
-    const int tid = threadIdx.x;
     const int lane = tid & 63, wc = tid >> 6;
-    const int f0 = tn * fpt;
-    const int fv = min(fpt, g.feat_limit - f0);
-
-    for (int i = tid; i < XM * fpt; i += XT) {
-        const int r = i / fpt, f = i - r * fpt;
-        float v = 0.f;
-        if (m0 + r < g.M && f < fv) v = g.x[(m0 + r) * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)];
-        xs[i] = v;
-    }
-
     const int kt_begin = g.ktab[2 * tn];
     const int kt_end = min(g.ktab[2 * tn + 1], (g.K + XS - 1) / XS);
 
-    const float hs = SP::SCALED ? g.hscale[0] : 1.f;    // power-of-two scale of this launch's hidden state
-    f32x16 acc[4][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const float bv = g.bias[tn * FN + wc * 64 + j * 32 + (lane & 31)] * (SP::SCALED ? g.scale[0] * hs : 1.f);
+        const float bv = g.bias[tn * FN + wc * 64 + j * 32 + (lane & 31)] * bscale;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -587,16 +581,12 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
         if (PRE) {                                                                                    \
             _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) t_[p_] = rp[p_];                        \
         } else {                                                                                      \
-            split_chunk<SP>(ra0, ra1, (kt_) * XS + ahalf * 8 < g.K, hs, t_);                            \
+            split_chunk<SP, RELU>(ra0, ra1, (kt_) * XS + ahalf * 8 < g.K, hs, t_);                          \
         }                                                                                             \
         _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) *reinterpret_cast<vec*>(sa_ + p_ * XA) = t_[p_]; \
         _Pragma("unroll") for (int q_ = 0; q_ < 2 * NT; ++q_)                                         \
             *reinterpret_cast<vec*>(sb_ + (q_ >> 1) * XB + (q_ & 1) * 128 * XLD) = rb[q_];            \
     }
-#ifdef NF_STAMP
-    long long tA = 0, tS = 0, tB = 0, tL = 0, tM = 0, tE = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0, t0 = clock64(), t1;
-    const long long tstart = t0;
-#endif
     // prologue: step 0 into stage 0, step 1 into the registers
     if (kt_begin < kt_end) {
         const int k1 = min(kt_begin + 1, kt_end - 1);
@@ -607,7 +597,6 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
         for (int n = 0; n < NP; ++n) X3_LOAD_PIECE(n, k1)
     }
     __syncthreads();
-    STAMP(tS)
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         const elem* sA = stage0 + cur * XSTAGE;
@@ -640,19 +629,54 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        STAMP(tM)
         __syncthreads();
-        STAMP(tA)
     }
 #undef X3_STORE
 #undef X3_LOAD_PIECE
 
+}
+
+template <class SP, int KT, bool INV, bool PRE>
+__global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g) {
+    constexpr int NT = SP::NT;
+    constexpr int XSTAGE = NT * (XA + XB);             // elements per stage
+    constexpr int XSTAGE_BYTES = 2 * 2 * XSTAGE;       // both stages
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int fpt = g.fpt, P = g.c.P;
+    const int ncol = fpt * P;
+    float* tile = (float*)lds;                       // epilogue: [ncol][XLDT], aliases the staging planes
+    float* xs = (float*)(lds + max(XSTAGE_BYTES, ncol * XLDT * 4));   // [128][fpt]
+    float* ldp = xs + XM * fpt;                      // [4 waves][128]
+
+    int64_t tm;
+    int tn;
+    tile_of_block(g, tm, tn);
+    const int64_t m0 = tm * XM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wc = tid >> 6;
+    const int f0 = tn * fpt;
+    const int fv = min(fpt, g.feat_limit - f0);
+
+    for (int i = tid; i < XM * fpt; i += XT) {
+        const int r = i / fpt, f = i - r * fpt;
+        float v = 0.f;
+        if (m0 + r < g.M && f < fv) v = g.x[(m0 + r) * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)];
+        xs[i] = v;
+    }
+
+    float ws = 1.f, wi = 1.f, hs = 1.f, hi = 1.f;      // power-of-two scales of the weights / of this launch's hidden state
+    if (SP::SCALED) {
+        pow2_pair(*g.wmax, ws, wi);
+        pow2_pair(*g.hmax, hs, hi);
+    }
+    f32x16 acc[4][2];
+    split_k_loop<SP, PRE, false>(g, lds, m0, tn, tid, ws * hs, hs, acc);
+
     // ---- epilogue: two passes of 64 samples (row blocks 2*half, 2*half + 1 of the accumulators) ------
-    const float oscale = SP::SCALED ? g.scale[1] * g.hscale[1] : 1.f;
+    const float oscale = wi * hi;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
-        STAMP(e0)
         {
             const int col = wc * 64 + (lane & 31);
             float* tp = tile + col * XLDT + 4 * (lane >> 5);
@@ -673,7 +697,6 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
                 }
         }
         __syncthreads();
-        STAMP(e1)
         float lsum = 0.f;                            // lane = sample row of the pass, wave-uniform feature
         const int r = half * XHR + lane;
         // a wave's (up to) three features of the pass in one straight-line block: the evaluations are
@@ -693,14 +716,11 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
                 if (f < fv) {
                     xs[r * fpt + f] = yv[u];
                     lsum += ld[u];
-#ifndef NF_STAMP
                     if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + f] = bin[u];
-#endif
                 }
             }
         }
         ldp[wc * XM + r] = lsum;
-        STAMP(e2)
     }
     __syncthreads();
     if (tid < XM) {
@@ -713,14 +733,54 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
         const int r = i / fpt, f = i - r * fpt;
         if (m0 + r < g.M && f < fv) g.y[(m0 + r) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = xs[i];
     }
-#ifdef NF_STAMP
-    STAMP(tE)
-    if (g.bins && lane == 0) {
-        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * (XT / 64) + wc) * 16;
-        dbg[0] = tA; dbg[1] = tS; dbg[2] = tB; dbg[3] = tL; dbg[4] = tM; dbg[5] = tE; dbg[6] = tstart;
-        dbg[7] = kt_end - kt_begin; dbg[8] = e0; dbg[9] = e1; dbg[10] = e2; dbg[11] = e3;
+}
+
+// Hidden-layer GEMM on split operands: y = [relu](x) @ (W * mask)^T + b (+ residual) [relu], fp32 in and out,
+// 128 x 256 output tiles through the same K loop.  The largest |y| goes to g.out_max (the next layer's operand
+// scale comes from it, so chained layers need no pass over their input).
+template <class SP, bool RELU>
+__global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int64_t tm;
+    int tn;
+    tile_of_block(g, tm, tn);
+    const int64_t m0 = tm * XM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wc = tid >> 6;
+    float ws = 1.f, wi = 1.f, hs = 1.f, hi = 1.f;
+    if (SP::SCALED) {
+        pow2_pair(*g.wmax, ws, wi);
+        pow2_pair(*g.hmax, hs, hi);
     }
-#endif
+    f32x16 acc[4][2];
+    split_k_loop<SP, false, RELU>(g, lds, m0, tn, tid, ws * hs, hs, acc);
+    const float oscale = wi * hi;
+    float vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = tn * FN + wc * 64 + j * 32 + (lane & 31);
+        if (col < g.N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < g.M) {
+                        float v = SP::SCALED ? acc[i][j][r] * oscale : acc[i][j][r];
+                        if (g.residual) v += g.residual[row * g.ldr + col];
+                        if (g.relu_out) v = fmaxf(v, 0.f);
+                        g.y[row * g.ldy + col] = v;
+                        const float a = fabsf(v);
+                        vmax = fmaxf(vmax, a < INFINITY ? a : 0.f);
+                    }
+                }
+        }
+    }
+    if (g.out_max) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0) atomicMax(g.out_max, __float_as_uint(vmax));
+    }
 }
 
 // packed[tile][step][term][row][16]: term t of W[n][k] * mask * fold (* the scale slot's power of two),
@@ -729,11 +789,12 @@ template <class SP>
 __global__ void pack_fused_split_kernel(const float* __restrict__ W, const float* __restrict__ mask,
                                         const float* __restrict__ bias, int out, int in, int src_rows, int kpad,
                                         int64_t total, int P, int n_logits, float logit_fold,
-                                        const float* __restrict__ scale, typename SP::elem* __restrict__ packed,
+                                        const unsigned* __restrict__ wmax, typename SP::elem* __restrict__ packed,
                                         float* __restrict__ bias_packed) {
     constexpr int NT = SP::NT;
     const int nsteps = kpad / XS;
-    const float sw = SP::SCALED ? scale[0] : 1.f;
+    float sw = 1.f, swi = 1.f;
+    if (SP::SCALED) pow2_pair(*wmax, sw, swi);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int kk = (int)(i % XS);
         const int j = (int)((i / XS) % FN);
@@ -760,9 +821,8 @@ __global__ void pack_fused_split_kernel(const float* __restrict__ W, const float
     }
 }
 
-// scale slot (two floats after the K-range table): [0] = 2^e with max |W * mask * fold| * 2^e in [2^13, 2^14),
-// [1] = 2^-e.  maxabs_kernel leaves the bit pattern of the maximum in slot[0] (positive floats order like
-// unsigned integers), scale_slot_kernel turns it into the pair.
+// scale slot (after the K-range table): the bit pattern of max |W * mask * fold| (positive floats order like
+// unsigned integers, so atomicMax works on the bits); consumers derive the power of two with pow2_pair.
 __global__ void maxabs_kernel(const float* __restrict__ W, const float* __restrict__ mask, int64_t total, int P, int in,
                               int n_logits, float logit_fold, unsigned* __restrict__ slot) {
     float m = 0.f;
@@ -779,19 +839,6 @@ __global__ void maxabs_kernel(const float* __restrict__ W, const float* __restri
     m = fmaxf(m, __shfl_xor(m, 2, 64));
     m = fmaxf(m, __shfl_xor(m, 1, 64));
     if ((threadIdx.x & 63) == 0 && m == m && m < INFINITY) atomicMax(slot, __float_as_uint(m));
-}
-
-__global__ void scale_slot_kernel(float* __restrict__ slot) {
-    const float m = slot[0];
-    int e = 0;
-    if (m > 0.f) {
-        int ex;
-        frexpf(m, &ex);                 // m = f * 2^ex, f in [0.5, 1)
-        e = 14 - ex;                    // m * 2^e in [2^13, 2^14)
-    }
-    e = max(-100, min(100, e));
-    slot[0] = ldexpf(1.f, e);
-    slot[1] = ldexpf(1.f, -e);
 }
 
 // largest finite |h| of h[M][K] into slot[0] (bit pattern, see above)
@@ -814,9 +861,10 @@ __global__ __launch_bounds__(256) void maxabs_rows_kernel(const float* __restric
 // h[M][K] fp32 -> NT term planes [NT][M][kp16], kp16 = K rounded up to whole 16-wide steps (zero filled)
 template <class SP>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ h, int64_t ldh, int64_t M, int K,
-                                                           int kp16, const float* __restrict__ hscale,
+                                                           int kp16, const unsigned* __restrict__ hmax,
                                                            typename SP::elem* __restrict__ planes) {
-    const float hs = SP::SCALED ? hscale[0] : 1.f;
+    float hs = 1.f, hi = 1.f;
+    if (SP::SCALED) pow2_pair(*hmax, hs, hi);
     const int cpr = kp16 / 8;                                  // 8-element chunks per row
     const int64_t total = M * cpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -866,23 +914,27 @@ int launch_k_split(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
 }
 
 // the split pre-pass (when the workspace has room for the planes and the launch covers the layer) + the kernel
+inline int maxabs_rows(const float* h, int64_t ld, int64_t B, int cols, unsigned* slot, hipStream_t s) {
+    hipError_t me = hipMemsetAsync(slot, 0, sizeof(unsigned), s);
+    if (me != hipSuccess) return (int)me;
+    const int64_t q4 = B * (cols / 4);
+    const int mgrid = (int)((q4 + 255) / 256 < 4096 ? (q4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(maxabs_rows_kernel, dim3(mgrid), dim3(256), 0, s, h, ld, B, cols, slot);
+    return nf_launch_status();
+}
+
 template <class SP>
-int run_split(FusedArgs& g, int grid, size_t lds, bool pre, const float* h, int64_t h_row_stride, int64_t B, int in,
-              int inverse, hipStream_t s) {
-    if (SP::SCALED) {
-        float* slot = const_cast<float*>(g.hscale);
-        hipError_t me = hipMemsetAsync(slot, 0, 2 * sizeof(float), s);
-        if (me != hipSuccess) return (int)me;
-        const int64_t q4 = B * (in / 4);
-        const int mgrid = (int)((q4 + 255) / 256 < 4096 ? (q4 + 255) / 256 : 4096);
-        hipLaunchKernelGGL(maxabs_rows_kernel, dim3(mgrid), dim3(256), 0, s, h, h_row_stride, B, in, (unsigned*)slot);
-        hipLaunchKernelGGL(scale_slot_kernel, dim3(1), dim3(1), 0, s, slot);
+int run_split(FusedArgs& g, int grid, size_t lds, bool pre, bool own_max, const float* h, int64_t h_row_stride,
+              int64_t B, int in, int inverse, hipStream_t s) {
+    if (SP::SCALED && own_max) {                       // no producer left max |h| in the slot: find it
+        const int rc = maxabs_rows(h, h_row_stride, B, in, const_cast<unsigned*>(g.hmax), s);
+        if (rc != NF_OK) return rc;
     }
     if (pre) {
         const int64_t chunks = B * (g.hp_ld / 8);
         const int sgrid = (int)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
         hipLaunchKernelGGL(split_planes_kernel<SP>, dim3(sgrid), dim3(256), 0, s, h, h_row_stride, B, in, (int)g.hp_ld,
-                           g.hscale, (typename SP::elem*)g.hp);
+                           g.hmax, (typename SP::elem*)g.hp);
         return inverse ? launch_k_split<SP, true, true>(g, grid, lds, s) : launch_k_split<SP, false, true>(g, grid, lds, s);
     }
     return inverse ? launch_k_split<SP, true, false>(g, grid, lds, s) : launch_k_split<SP, false, false>(g, grid, lds, s);
@@ -965,20 +1017,18 @@ extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const 
     hipStream_t s = (hipStream_t)stream;
     if (dtype == NF_DTYPE_BF16X3) {
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x3>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in,
-                           fpt * P, kpad, 3 * total, P, 2 * K, logit_fold, (const float*)nullptr, (__bf16*)packed,
+                           fpt * P, kpad, 3 * total, P, 2 * K, logit_fold, (const unsigned*)nullptr, (__bf16*)packed,
                            bias_packed);
     } else if (dtype == NF_DTYPE_F16X2) {
         if (!ktab) return NF_ERR_NULL;                 // the scale pair lives after the table
-        float* slot = (float*)(ktab + 2 * nt);
-        hipError_t me = hipMemsetAsync(slot, 0, 2 * sizeof(float), s);
+        unsigned* slot = (unsigned*)(ktab + 2 * nt);
+        hipError_t me = hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), s);
         if (me != hipSuccess) return (int)me;
         const int64_t nw = (int64_t)out * in;
         const int mgrid = (int)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
-        hipLaunchKernelGGL(maxabs_kernel, dim3(mgrid), dim3(256), 0, s, W, mask, nw, P, in, 2 * K, logit_fold,
-                           (unsigned*)slot);
-        hipLaunchKernelGGL(scale_slot_kernel, dim3(1), dim3(1), 0, s, slot);
+        hipLaunchKernelGGL(maxabs_kernel, dim3(mgrid), dim3(256), 0, s, W, mask, nw, P, in, 2 * K, logit_fold, slot);
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitF16x2>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in,
-                           fpt * P, kpad, 2 * total, P, 2 * K, logit_fold, (const float*)slot, (_Float16*)packed,
+                           fpt * P, kpad, 2 * total, P, 2 * K, logit_fold, (const unsigned*)slot, (_Float16*)packed,
                            bias_packed);
     } else if (dtype == NF_DTYPE_F32)
         hipLaunchKernelGGL(pack_fused_kernel<float>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
@@ -1001,7 +1051,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
                           int accumulate, int32_t* bin_idx, float* workspace, size_t workspace_bytes, int64_t B, int in,
                           int features, int K, int tails, double tail_bound, double min_bin_width,
                           double min_bin_height, double min_derivative, int inverse, int dtype, int tile_begin,
-                          int tile_count, int feat_limit, int reduce, void* stream) {
+                          int tile_count, int feat_limit, int reduce, const unsigned* h_max, void* stream) {
     if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
     if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && !split_terms(dtype)) return NF_ERR_DTYPE;
@@ -1015,7 +1065,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     FusedArgs g;
     g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
-    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hscale = nullptr;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = nullptr;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
@@ -1024,7 +1074,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     g.tn0 = tile_begin;
     g.feat_limit = feat_limit;
     const bool x3 = split_terms(dtype) != 0;
-    g.scale = (const float*)(ktab + 2 * all_tiles);
+    g.wmax = (const unsigned*)(ktab + 2 * all_tiles);
     g.m_tiles = x3 ? (B + XM - 1) / XM : (B + FM - 1) / FM;
     g.group_m = x3 ? 8 : 16;
     const int64_t grid = g.m_tiles * g.n_tiles;
@@ -1039,14 +1089,14 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
             // launches of the incremental inverse split it on the way into LDS instead
             const size_t part = (nf_made_rqs_workspace_bytes(B, features, K, tails) + 255) / 256 * 256;
             if (workspace_bytes < part + 256) return NF_ERR_SCRATCH;      // the hidden-state scale slot
-            g.hscale = (const float*)((const char*)workspace + part);
+            g.hmax = h_max ? h_max : (const unsigned*)((const char*)workspace + part);
             const bool pre = tile_count == all_tiles && workspace_bytes >= part + 256 + planes_bytes(B, in, dtype);
             if (pre) {
                 g.hp = (const char*)workspace + part + 256;
                 g.hp_ld = kp16_of(in);
             }
-            rc = dtype == NF_DTYPE_BF16X3 ? run_split<SplitBf16x3>(g, (int)grid, lds, pre, h, h_row_stride, B, in, inverse, s)
-                                          : run_split<SplitF16x2>(g, (int)grid, lds, pre, h, h_row_stride, B, in, inverse, s);
+            rc = dtype == NF_DTYPE_BF16X3 ? run_split<SplitBf16x3>(g, (int)grid, lds, pre, h_max == nullptr, h, h_row_stride, B, in, inverse, s)
+                                          : run_split<SplitF16x2>(g, (int)grid, lds, pre, h_max == nullptr, h, h_row_stride, B, in, inverse, s);
         }
         else if (dtype == NF_DTYPE_BF16)
             rc = inverse ? launch_k<true, true>(g, (int)grid, lds, s) : launch_k<true, false>(g, (int)grid, lds, s);
@@ -1069,7 +1119,7 @@ extern "C" int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const
     return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr,
                           features, logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
                           tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, tile_begin,
-                          tile_count, feat_limit, reduce, stream);
+                          tile_count, feat_limit, reduce, nullptr, stream);
 }
 
 extern "C" int nf_coupling_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
@@ -1084,7 +1134,20 @@ extern "C" int nf_coupling_rqs_fwd(const float* h, int64_t h_row_stride, const v
     return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, feat_index,
                           row_width, logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K,
                           tails, tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
-                          nf_made_rqs_tiles(features, K, tails), features, 1, stream);
+                          nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, stream);
+}
+
+// nf_made_rqs_fwd with the producer's max |h| slot (split-operand dtypes: skips the max pre-pass)
+extern "C" int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h_max, const void* packed_w,
+                                    const int32_t* ktab, const float* bias_packed, const float* x, int64_t x_row_stride,
+                                    float* y, int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                                    float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
+                                    int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                                    double min_derivative, int inverse, int dtype, void* stream) {
+    return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr,
+                          features, logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
+                          tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
+                          nf_made_rqs_tiles(features, K, tails), features, 1, (const unsigned*)h_max, stream);
 }
 
 extern "C" int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
@@ -1097,4 +1160,94 @@ extern "C" int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void*
                                  logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
                                  tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
                                  nf_made_rqs_tiles(features, K, tails), features, 1, stream);
+}
+
+// ---- split-operand hidden-layer GEMM ------------------------------------------------------------------
+extern "C" int nf_linear_split_tiles(int out) { return out <= 0 ? 0 : (out + FN - 1) / FN; }
+
+extern "C" size_t nf_linear_split_packed_bytes(int out, int in, int dtype) {
+    if (out <= 0 || in <= 0 || !split_terms(dtype)) return 0;
+    return (size_t)nf_linear_split_tiles(out) * FN * kpad_of(in) * 2 * split_terms(dtype);
+}
+
+extern "C" int nf_linear_split_pack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
+                                    void* packed, int32_t* ktab, float* bias_packed, void* stream) {
+    if (!W || !packed || !ktab || !bias_packed) return NF_ERR_NULL;
+    if (out <= 0 || in <= 0) return NF_ERR_SHAPE;
+    if (!split_terms(dtype)) return NF_ERR_DTYPE;
+    const int nt = nf_linear_split_tiles(out), kpad = kpad_of(in), terms = split_terms(dtype);
+    const int64_t total = (int64_t)terms * nt * FN * kpad;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* slot = (unsigned*)(ktab + 2 * nt);
+    hipError_t me = hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), s);
+    if (me != hipSuccess) return (int)me;
+    if (dtype == NF_DTYPE_F16X2) {
+        const int64_t nw = (int64_t)out * in;
+        const int mgrid = (int)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
+        hipLaunchKernelGGL(maxabs_kernel, dim3(mgrid), dim3(256), 0, s, W, mask, nw, 1, in, 0, 1.0f, slot);
+        hipLaunchKernelGGL(pack_fused_split_kernel<SplitF16x2>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
+                           kpad, total, 1, 0, 1.0f, (const unsigned*)slot, (_Float16*)packed, bias_packed);
+    } else {
+        hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x3>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
+                           kpad, total, 1, 0, 1.0f, (const unsigned*)nullptr, (__bf16*)packed, bias_packed);
+    }
+    hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, FN, ktab);
+    return nf_launch_status();
+}
+
+extern "C" int nf_maxabs(const float* x, int64_t x_row_stride, int64_t B, int cols, uint32_t* slot, void* stream) {
+    if (B < 0 || cols <= 0 || cols % 4 != 0) return NF_ERR_SHAPE;
+    if (!slot) return NF_ERR_NULL;
+    if (B == 0) return (int)hipMemsetAsync(slot, 0, sizeof(uint32_t), (hipStream_t)stream);
+    if (!x) return NF_ERR_NULL;
+    if (x_row_stride < cols || x_row_stride % 4 != 0 || ((uintptr_t)x & 15) != 0) return NF_ERR_LAYOUT;
+    return maxabs_rows(x, x_row_stride, B, cols, (unsigned*)slot, (hipStream_t)stream);
+}
+
+template <class SP>
+static int launch_linear_split(const FusedArgs& g, int grid, size_t lds, int relu_in, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)masked_linear_split_kernel<SP, false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e2 = hipFuncSetAttribute((const void*)masked_linear_split_kernel<SP, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e1 != hipSuccess) return (int)e1;
+        if (e2 != hipSuccess) return (int)e2;
+        attr_set = true;
+    }
+    if (relu_in) hipLaunchKernelGGL((masked_linear_split_kernel<SP, true>), dim3(grid), dim3(XT), lds, s, g);
+    else hipLaunchKernelGGL((masked_linear_split_kernel<SP, false>), dim3(grid), dim3(XT), lds, s, g);
+    return nf_launch_status();
+}
+
+extern "C" int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                          const void* packed_w, const int32_t* ktab, const float* bias_packed,
+                                          const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride,
+                                          uint32_t* y_max, int64_t B, int in, int out, int relu_in, int relu_out,
+                                          int dtype, void* stream) {
+    if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
+    if (!split_terms(dtype)) return NF_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (y_max) {
+        hipError_t me = hipMemsetAsync(y_max, 0, sizeof(uint32_t), s);
+        if (me != hipSuccess) return (int)me;
+    }
+    if (B == 0) return NF_OK;
+    if (!x || !packed_w || !ktab || !bias_packed || !y || (dtype == NF_DTYPE_F16X2 && !x_max)) return NF_ERR_NULL;
+    if (x_row_stride < in || y_row_stride < out || (residual && res_row_stride < out)) return NF_ERR_LAYOUT;
+    if (in % 8 != 0 || x_row_stride % 4 != 0 || ((uintptr_t)x & 15) != 0) return NF_ERR_LAYOUT;
+    FusedArgs g = {};
+    const int nt = nf_linear_split_tiles(out);
+    g.h = x; g.ldh = x_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
+    g.y = y; g.ldy = y_row_stride; g.M = B; g.K = in; g.N = out; g.n_tiles = nt; g.tn0 = 0;
+    g.m_tiles = (B + XM - 1) / XM; g.group_m = 8;
+    g.wmax = (const unsigned*)(ktab + 2 * nt); g.hmax = (const unsigned*)x_max;
+    g.residual = residual; g.ldr = res_row_stride; g.relu_out = relu_out; g.out_max = (unsigned*)y_max;
+    const int64_t grid = g.m_tiles * nt;
+    if (grid > 0x7fffffff) return NF_ERR_SHAPE;
+    const size_t lds = (size_t)2 * 2 * split_terms(dtype) * (XA + XB);
+    return dtype == NF_DTYPE_BF16X3 ? launch_linear_split<SplitBf16x3>(g, (int)grid, lds, relu_in, s)
+                                    : launch_linear_split<SplitF16x2>(g, (int)grid, lds, relu_in, s);
 }

@@ -18,7 +18,8 @@ from . import _lib
 
 _MATMUL_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_BF16X3,
                  'f16x2': _lib.NF_DTYPE_F16X2}
-# the hidden-layer GEMMs have no split-bf16 kernel yet: they stay on the fp32 matrix path in that mode
+_SPLIT_MODES = ('bf16x3', 'f16x2')
+# hidden-layer GEMMs the split kernel does not take (BatchNorm prologue, tile windows, ragged K) stay on fp32 MFMA
 _GEMM_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_F32,
                'f16x2': _lib.NF_DTYPE_F32}
 _default_matmul = 'f32'
@@ -79,6 +80,18 @@ class _PackedMixin:
             cached = self._pack_cache
         return cached[1]
 
+    def _packed_linear_split(self):
+        """Term-plane pack for the split-operand hidden-layer kernel (nf_linear_split_pack), cached likewise."""
+        mask = getattr(self, 'mask', None)
+        key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
+               get_matmul_dtype(), self.weight.device, None if mask is None else (mask._version, mask.data_ptr()))
+        cached = getattr(self, '_split_cache', None)
+        if cached is None or cached[0] != key:
+            pls = _lib.PackedLinearSplit(self.weight, mask, self.bias, _MATMUL_DTYPE[get_matmul_dtype()])
+            object.__setattr__(self, '_split_cache', (key, pls))
+            cached = self._split_cache
+        return cached[1]
+
     def _packed_fused_final(self, features, num_bins, tails, logit_div=1.0):
         """Final layer regrouped for the fused GEMM + spline kernel (nf_made_rqs_pack), cached likewise."""
         key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
@@ -112,6 +125,10 @@ class _PackedMixin:
                 raise NotImplementedError('no backward kernel for BatchNorm / feed-forward blocks')
             from .autograd import MaskedLinearFn
             return MaskedLinearFn.apply(x, self.weight, self.bias, residual, self, bool(relu_in))
+        if (get_matmul_dtype() in _SPLIT_MODES and in_scale is None and in_shift is None and tiles is None
+                and _lib.split_gemm_supported(x, self.in_features)):
+            return _lib.masked_linear_split(x, self._packed_linear_split(), residual=residual, relu_in=relu_in,
+                                            relu_out=relu_out, out=out)
         return _lib.masked_linear(x, self._packed_linear(), residual=residual, in_scale=in_scale,
                                   in_shift=in_shift, relu_in=relu_in, relu_out=relu_out, out=out, tiles=tiles)
 
