@@ -438,11 +438,13 @@ __global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict
 //
 // Shape: a 256-thread workgroup owns 128 samples x 256 parameter columns (11 whole features at P = 23);
 // each of its 4 waves holds a 128 x 64 accumulator (4 x 2 MFMA tiles, 128 VGPRs), two workgroups per CU.
-// K loop: 16-wide steps, LDS double buffered, ONE barrier per step: while the 48 MFMAs of step k run,
-// the registers holding step k+1 go to the other LDS stage and the loads of step k+2 are issued, one
-// in front of each group of six MFMAs.
-// Weights are split once at pack time ([tile][16-wide K step][term][256 rows][16]: one contiguous chunk
-// per step); the hidden state is split by a pre-pass (whole-layer launches) or on its way into LDS.
+// K loop (split_k_loop): 16-wide steps, ONE barrier per step.  The A operand (the 128 samples, shared by the
+// four waves) goes through double-buffered LDS: while a step's MFMAs run, the registers holding step k+1 go
+// to the other stage and the loads of a later step are issued, one in front of each group of MFMAs.  The
+// B operand (weights) is private to a wave, so it skips LDS: packed at pack time in MFMA operand order
+// ([tile][step][wave][j][term][lane][8]), it is loaded from global memory straight into the operand
+// registers, two register sets deep.  The hidden state is split into term planes by a pre-pass
+// (whole-layer launches) or on its way into LDS (windowed launches of the inverse).
 // Epilogue as in the fp32 kernel, 64 samples per pass.
 //
 // Split-fp16 ("f16x2") flavour of the same kernel: two fp16 terms a = a0 + a1 (11 + 11 mantissa bits),
@@ -453,12 +455,25 @@ __global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict
 // keeps 22 bits unless it is 2^-14 times smaller than the largest one (then 2^-39 of that one, absolute).
 // Half the matrix work and 2/3 of the operand traffic of bf16x3 - this kernel is power-limited, not
 // issue-limited (the clock drops to ~1.7 GHz under it), so energy per product is what buys time.
+// knock-out switches for timing experiments (benchmarks/build_variant.sh): results are wrong with any of them set
+#ifndef NF_KO_STORE
+#define NF_KO_STORE 0
+#endif
+#ifndef NF_KO_LOADS
+#define NF_KO_LOADS 0
+#endif
+#ifndef NF_KO_MMA
+#define NF_KO_MMA 0
+#endif
+#ifndef NF_KO_EVAL
+#define NF_KO_EVAL 0
+#endif
 constexpr int XM = 128, XT = 256, XS = 16;     // samples per workgroup, threads, K elements per step
-// LDS stage = NT term planes of A [128 rows][32 B] and of B [256 rows][32 B], rows unpadded; the two
-// 16-byte halves of a row are swapped when bit 3 of the row is set, which makes the MFMA operand reads
-// (ds_read_b128, lane = row, lane groups {0-3,12-15,20-27}...) conflict-free.  Two stages (double buffer).
+// LDS stage = NT term planes of A [128 rows][32 B], rows unpadded; the two 16-byte halves of a row are
+// swapped when bit 3 of the row is set, which makes the MFMA operand reads (ds_read_b128, lane = row, lane
+// groups {0-3,12-15,20-27}...) conflict-free.  Two stages (double buffer).
 constexpr int XLD = 16;                        // 16-bit elements per LDS row
-constexpr int XA = XM * XLD, XB = FN * XLD;    // elements per term plane
+constexpr int XA = XM * XLD;                    // elements per A term plane of an LDS stage
 constexpr int XHR = 64, XLDT = XHR + 4;        // epilogue pass and its column-major tile stride
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -526,17 +541,20 @@ __device__ __forceinline__ void split_chunk(const float4& lo, const float4& hi, 
 
 // The K loop shared by the split-operand kernels: acc (+)= A[m0.., :] @ Wpacked[tile tn]^T over the tile's live
 // 16-wide K steps, accumulators started at bias * bscale.  A comes from g.h (fp32, split on the fly with scale
-// hs, ReLU first when RELU) or, PRE, from the term planes g.hp.
+// hs, ReLU first when RELU) or, PRE, from the term planes g.hp, and is shared by the four waves through LDS
+// (double buffered, one barrier per step).  B is not shared - a wave multiplies only its own 64 columns - so
+// it never touches LDS: the packed weights are laid out in MFMA operand order ([tile][step][wave][j][term]
+// [lane][8]: 1 KB per wave-instruction, fully coalesced) and go from global memory straight into the operand
+// registers, two register sets deep (a set is refilled for step k+2 as soon as step k has used it).
 template <class SP, bool PRE, bool RELU>
 __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int64_t m0, int tn, int tid, float bscale,
                                              float hs, f32x16 (&acc)[4][2]) {
     constexpr int NT = SP::NT;
-    constexpr int XSTAGE = NT * (XA + XB);             // elements per stage
-    constexpr int XUNITS = NT * FN * XS / 8;           // 16-byte units of one packed weight step
-    constexpr int NP = 3 * NT;                         // load pieces per step: NT of A, 2 NT of B
+    constexpr int XSTAGE = NT * XA;                    // elements per LDS stage (A term planes only)
+    constexpr int BSTEP = 4 * 2 * NT * 64;             // 16-byte units of one packed weight step (all 4 waves)
     typedef typename SP::vec vec;
     typedef typename SP::elem elem;
-    elem* stage0 = (elem*)lds;                       // stage s at stage0 + s * XSTAGE: A planes, then B planes
+    elem* stage0 = (elem*)lds;
     const int lane = tid & 63, wc = tid >> 6;
     const int kt_begin = g.ktab[2 * tn];
     const int kt_end = min(g.ktab[2 * tn + 1], (g.K + XS - 1) / XS);
@@ -550,97 +568,105 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
             for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
     }
 
-    // staging: A - thread owns 8 consecutive k of one row; B - six 16-byte units of the step's packed chunk
-    // (PRE: the hidden state arrives already split into term planes, zero padded to whole steps)
+    // A staging: thread owns 8 consecutive k of one row (PRE: per term plane, zero padded to whole steps)
     const int arow = tid >> 1, ahalf = tid & 1;
     const float* ap = g.h + min(m0 + arow, g.M - 1) * g.ldh;
     const elem* app = (const elem*)g.hp + min(m0 + arow, g.M - 1) * g.hp_ld + ahalf * 8;
     const int64_t aplane = g.M * g.hp_ld;
-    const vec* bp = (const vec*)g.w + (int64_t)tn * (g.kpad / XS) * XUNITS + tid;
+    const vec* bp = (const vec*)g.w + ((int64_t)tn * (g.kpad / XS) * 4 + wc) * (2 * NT * 64) + lane;
     // LDS element offsets inside a stage: row * 16 + (half ^ bit 3 of the row) * 8
-    const int woff = arow * XLD + ((ahalf ^ ((arow >> 3) & 1)) * 8);          // rows arow (A, B) and arow + 128 (B)
+    const int woff = arow * XLD + ((ahalf ^ ((arow >> 3) & 1)) * 8);
     const int frow = lane & 31;
     const int roff = frow * XLD + (((lane >> 5) ^ ((frow >> 3) & 1)) * 8);
-    float4 ra0, ra1;
-    vec rp[NT], rb[2 * NT];
-#define X3_LOAD_PIECE(n_, kt_)                                                                        \
+    // NSET register sets of staged A: with two (the two-term flavour has the registers for it) a load issued
+    // during step k is consumed during step k+2 - a 768-cycle step alone does not cover an L2 round trip
+    constexpr int NSET = NT == 2 ? 2 : 1;
+    float4 ra[NSET][2];
+    vec rp[NSET][NT];
+    vec b[2][2][NT];                                   // [register set = step parity][j][term]
+#define X3_LOAD_A(s_, n_, kt_)                                                                        \
     {                                                                                                 \
-        if ((n_) < NT) {                                                                              \
-            if (PRE) rp[(n_) < NT ? (n_) : 0] = *reinterpret_cast<const vec*>(app + (n_) * aplane + (kt_) * XS); \
-            else if ((n_) == 0) ra0 = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8));   \
-            else if ((n_) == 1) ra1 = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8) + 4); \
-        } else {                                                                                      \
-            rb[(n_) >= NT ? (n_) - NT : 0] = bp[(int64_t)(kt_) * XUNITS + 256 * ((n_) - NT)];         \
-        }                                                                                             \
+        if (PRE) rp[s_][n_] = *reinterpret_cast<const vec*>(app + (n_) * aplane + (kt_) * XS);        \
+        else if ((n_) < 2) ra[s_][(n_) & 1] = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8) + 4 * (n_)); \
     }
-#define X3_STORE(st_, kt_)                                                                            \
+#define X3_LOAD_B(s_, j_, kt_)                                                                        \
+    {                                                                                                 \
+        _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_)                                             \
+            b[s_][j_][p_] = bp[(int64_t)(kt_) * BSTEP + ((j_) * NT + p_) * 64];                       \
+    }
+#define X3_STORE_A(s_, st_, kt_)                                                                      \
     {                                                                                                 \
         elem* sa_ = (st_) + woff;                                                                     \
-        elem* sb_ = (st_) + NT * XA + woff;                                                           \
         vec t_[NT];                                                                                   \
         if (PRE) {                                                                                    \
-            _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) t_[p_] = rp[p_];                        \
+            _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) t_[p_] = rp[s_][p_];                    \
         } else {                                                                                      \
-            split_chunk<SP, RELU>(ra0, ra1, (kt_) * XS + ahalf * 8 < g.K, hs, t_);                          \
+            split_chunk<SP, RELU>(ra[s_][0], ra[s_][1], (kt_) * XS + ahalf * 8 < g.K, hs, t_);        \
         }                                                                                             \
         _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) *reinterpret_cast<vec*>(sa_ + p_ * XA) = t_[p_]; \
-        _Pragma("unroll") for (int q_ = 0; q_ < 2 * NT; ++q_)                                         \
-            *reinterpret_cast<vec*>(sb_ + (q_ >> 1) * XB + (q_ & 1) * 128 * XLD) = rb[q_];            \
     }
-    // prologue: step 0 into stage 0, step 1 into the registers
+    // one K step on LDS stage / B register set (par_): 8 groups of MFMAs; in front of group 1 the A register
+    // set (s_) - step kt+1 - goes to the other LDS stage, in front of groups 2.. its refill loads for step
+    // kt+1+NSET; B set (par_) is refilled for step kt+2 half by half as the j = 0 / j = 1 groups finish
+#define X3_STEP(s_, par_, kt_)                                                                        \
+    {                                                                                                 \
+        const elem* sA = stage0 + (par_) * XSTAGE;                                                    \
+        elem* nxt = stage0 + ((par_) ^ 1) * XSTAGE;                                                   \
+        const int kt1 = min((kt_) + 1, kt_end - 1), kta = min((kt_) + 1 + NSET, kt_end - 1);          \
+        const int ktb = min((kt_) + 2, kt_end - 1);                                                   \
+        vec a[4][NT];                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+            _Pragma("unroll") for (int p = 0; p < NT; ++p)                                            \
+                a[i][p] = *reinterpret_cast<const vec*>(sA + p * XA + i * 32 * XLD + roff);           \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+                const int grp = j * 4 + i;                                                            \
+                if (grp == 1 && !NF_KO_STORE) X3_STORE_A(s_, nxt, kt1)                                \
+                if (!NF_KO_LOADS) {                                                                   \
+                    _Pragma("unroll") for (int n = 0; n < NT; ++n)                                    \
+                        if (grp == 2 + n) X3_LOAD_A(s_, n, kta)                                       \
+                    if (grp == 5) X3_LOAD_B(par_, 0, ktb)                                             \
+                }                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                    \
+                if (!NF_KO_MMA) SP::fma_tile(acc[i][j], a[i], b[par_][j]);                            \
+                __builtin_amdgcn_sched_barrier(0);                                                    \
+            }                                                                                         \
+        }                                                                                             \
+        if (!NF_KO_LOADS) X3_LOAD_B(par_, 1, ktb)                                                     \
+        __syncthreads();                                                                              \
+    }
+    // prologue: A step 0 into stage 0 and steps 1 .. NSET into the register sets; B steps 0 and 1
     if (kt_begin < kt_end) {
-        const int k1 = min(kt_begin + 1, kt_end - 1);
 #pragma unroll
-        for (int n = 0; n < NP; ++n) X3_LOAD_PIECE(n, kt_begin)
-        X3_STORE(stage0, kt_begin)
+        for (int n = 0; n < NT; ++n) X3_LOAD_A(0, n, kt_begin)
+        X3_LOAD_B(0, 0, kt_begin)
+        X3_LOAD_B(0, 1, kt_begin)
+        X3_STORE_A(0, stage0, kt_begin)
+        const int kb1 = min(kt_begin + 1, kt_end - 1);
+        X3_LOAD_B(1, 0, kb1)
+        X3_LOAD_B(1, 1, kb1)
 #pragma unroll
-        for (int n = 0; n < NP; ++n) X3_LOAD_PIECE(n, k1)
+        for (int q = 0; q < NSET; ++q) {
+            const int kq = min(kt_begin + 1 + q, kt_end - 1);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) X3_LOAD_A(q, n, kq)
+        }
     }
     __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        const elem* sA = stage0 + cur * XSTAGE;
-        const elem* sB = sA + NT * XA;
-        elem* nxt = stage0 + (cur ^ 1) * XSTAGE;
-        const int kt1 = min(kt + 1, kt_end - 1), kt2 = min(kt + 2, kt_end - 1);
-        vec a[4][NT];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int p = 0; p < NT; ++p)
-                a[i][p] = *reinterpret_cast<const vec*>(sA + p * XA + i * 32 * XLD + roff);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            vec b[NT];
-#pragma unroll
-            for (int p = 0; p < NT; ++p)
-                b[p] = *reinterpret_cast<const vec*>(sB + p * XB + (wc * 64 + j * 32) * XLD + roff);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int grp = j * 4 + i;
-                // group 1: the registers (step kt+1, loaded a whole step ago) go to the other stage;
-                // groups 2..7: the loads of step kt+2, spread under the matrix work
-                if (grp == 1) X3_STORE(nxt, kt1)
-#pragma unroll
-                for (int n = 0; n < NP; ++n)
-                    if (grp == 2 + (n * 6) / NP) X3_LOAD_PIECE(n, kt2)
-                __builtin_amdgcn_sched_barrier(0);
-                SP::fma_tile(acc[i][j], a[i], b);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        X3_STEP(0, 0, kt)
+        if (kt + 1 < kt_end) X3_STEP(NSET - 1, 1, kt + 1)
     }
-#undef X3_STORE
-#undef X3_LOAD_PIECE
-
+#undef X3_STEP
+#undef X3_STORE_A
+#undef X3_LOAD_B
+#undef X3_LOAD_A
 }
 
 template <class SP, int KT, bool INV, bool PRE>
 __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g) {
     constexpr int NT = SP::NT;
-    constexpr int XSTAGE = NT * (XA + XB);             // elements per stage
-    constexpr int XSTAGE_BYTES = 2 * 2 * XSTAGE;       // both stages
+    constexpr int XSTAGE_BYTES = 2 * 2 * NT * XA;      // both LDS stages of the A term planes
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int fpt = g.fpt, P = g.c.P;
     const int ncol = fpt * P;
@@ -708,7 +734,8 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int f = min(fb + u * (XT / 64), fv - 1);
-                rqs_eval<KT, INV, XLDT, true, true>(tile + f * P * XLDT + lane, xs[r * fpt + f], g.c, yv[u], ld[u], bin[u]);
+                if (NF_KO_EVAL) { yv[u] = tile[f * P * XLDT + lane]; ld[u] = yv[u]; bin[u] = 0; }
+                else rqs_eval<KT, INV, XLDT, true, true>(tile + f * P * XLDT + lane, xs[r * fpt + f], g.c, yv[u], ld[u], bin[u]);
             }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
@@ -783,8 +810,9 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
     }
 }
 
-// packed[tile][step][term][row][16]: term t of W[n][k] * mask * fold (* the scale slot's power of two),
-// n = tile*src_rows + row, k = step*16 + kk
+// packed[tile][step][wave 0..3][j 0..1][term][lane 0..63][8]: the 8 elements lane `lane` feeds to the MFMA as
+// the B operand of column block j of wave `wave` - row = wave*64 + j*32 + (lane & 31) of the tile,
+// k = step*16 + (lane >> 5)*8 + e - i.e. term t of W[n][k] * mask * fold (* the scale slot's power of two)
 template <class SP>
 __global__ void pack_fused_split_kernel(const float* __restrict__ W, const float* __restrict__ mask,
                                         const float* __restrict__ bias, int out, int in, int src_rows, int kpad,
@@ -796,12 +824,15 @@ __global__ void pack_fused_split_kernel(const float* __restrict__ W, const float
     float sw = 1.f, swi = 1.f;
     if (SP::SCALED) pow2_pair(*wmax, sw, swi);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int kk = (int)(i % XS);
-        const int j = (int)((i / XS) % FN);
-        const int term = (int)((i / (XS * FN)) % NT);
-        const int step = (int)((i / (NT * XS * FN)) % nsteps);
-        const int tn = (int)(i / ((int64_t)NT * XS * FN * nsteps));
-        const int k = step * XS + kk;
+        const int e = (int)(i % 8);
+        const int lane = (int)((i / 8) % 64);
+        const int term = (int)((i / 512) % NT);
+        const int jj = (int)((i / (512 * NT)) % 2);
+        const int w = (int)((i / (1024 * NT)) % 4);
+        const int step = (int)((i / (4096 * NT)) % nsteps);
+        const int tn = (int)(i / ((int64_t)4096 * NT * nsteps));
+        const int j = w * 64 + jj * 32 + (lane & 31);          // row of the 256-row tile
+        const int k = step * XS + (lane >> 5) * 8 + e;
         const int64_t n = (int64_t)tn * src_rows + j;
         const bool live = j < src_rows && n < out;
         const float fold = (j % P) < n_logits ? logit_fold : 1.0f;
@@ -886,7 +917,7 @@ inline size_t planes_bytes(int64_t B, int in, int dtype) { return (size_t)split_
 
 inline size_t lds_bytes_split(int fpt, int P, int nt) {
     const size_t tile = sizeof(float) * (size_t)fpt * P * XLDT;
-    const size_t stages = (size_t)2 * 2 * nt * (XA + XB);
+    const size_t stages = (size_t)2 * 2 * nt * XA;
     return (tile > stages ? tile : stages) + sizeof(float) * ((size_t)XM * fpt + (size_t)XM * (XT / 64));
 }
 
@@ -1247,7 +1278,7 @@ extern "C" int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, 
     g.residual = residual; g.ldr = res_row_stride; g.relu_out = relu_out; g.out_max = (unsigned*)y_max;
     const int64_t grid = g.m_tiles * nt;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    const size_t lds = (size_t)2 * 2 * split_terms(dtype) * (XA + XB);
+    const size_t lds = (size_t)2 * 2 * split_terms(dtype) * XA;
     return dtype == NF_DTYPE_BF16X3 ? launch_linear_split<SplitBf16x3>(g, (int)grid, lds, relu_in, s)
                                     : launch_linear_split<SplitF16x2>(g, (int)grid, lds, relu_in, s);
 }
