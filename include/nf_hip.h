@@ -167,10 +167,11 @@ int nf_coupling_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed
                         double min_bin_height, double min_derivative, int inverse, int dtype, void* stream);
 
 /* nf_made_rqs_fwd with `h_max`: the slot a split-operand producer (nf_masked_linear_split_fwd's y_max) left
- * max |h| in, which saves the kernel's own pass over h.  NULL = nf_made_rqs_fwd. */
+ * max |h| in, which saves the kernel's own pass over h (NULL: as nf_made_rqs_fwd), and `y_max` (nullable,
+ * split-operand dtypes only): receives max |y| for the next layer's first GEMM. */
 int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h_max, const void* packed_w,
                          const int32_t* ktab, const float* bias_packed, const float* x, int64_t x_row_stride,
-                         float* y, int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                         float* y, int64_t y_row_stride, uint32_t* y_max, float* logabsdet, int accumulate, int32_t* bin_idx,
                          float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
                          int tails, double tail_bound, double min_bin_width, double min_bin_height,
                          double min_derivative, int inverse, int dtype, void* stream);

@@ -67,7 +67,7 @@ _SIGNATURES = {
                                        _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
                                        _c.c_double, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_made_rqs_fwd_hmax': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
-                                        _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int,
+                                        _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int,
                                         _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                         _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
                                         _c.c_int, _c.c_void_p]),
@@ -408,8 +408,10 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
     tb, tc = (0, pf.tiles) if tiles is None else tiles
     fl = pf.features if feat_limit is None else feat_limit
     # a split-operand producer left max |h| beside the tensor: whole-layer launches can skip their own pass
-    h_max = getattr(h, '_nf_max', None) if (tiles is None and feat_limit is None and feat_index is None
-                                            and pf.dtype == NF_DTYPE_F16X2) else None
+    whole_split = (tiles is None and feat_limit is None and feat_index is None
+                   and pf.dtype in (NF_DTYPE_F16X2, NF_DTYPE_BF16X3))
+    h_max = getattr(h, '_nf_max', None) if whole_split else None
+    y_max = torch.empty(1, dtype=torch.int32, device=x.device) if whole_split else None
 
     def launch():
         if feat_index is not None:
@@ -419,9 +421,10 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
                                            pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
                                            float(min_bin_height), float(min_derivative), int(inverse), pf.dtype,
                                            _stream())
-        if h_max is not None:
-            return lib.nf_made_rqs_fwd_hmax(hp, hs, h_max.data_ptr(), pf.packed.data_ptr(), pf.ktab.data_ptr(),
-                                            pf.bias.data_ptr(), xp, xs, yp, ys, logabsdet.data_ptr(), int(accumulate),
+        if whole_split:
+            return lib.nf_made_rqs_fwd_hmax(hp, hs, _ptr(h_max), pf.packed.data_ptr(), pf.ktab.data_ptr(),
+                                            pf.bias.data_ptr(), xp, xs, yp, ys, y_max.data_ptr(), logabsdet.data_ptr(),
+                                            int(accumulate),
                                             _ptr(bins), ws.data_ptr(), ws.numel() * 4, B, pf.inp, pf.features, pf.K,
                                             pf.tails, float(tail_bound), float(min_bin_width), float(min_bin_height),
                                             float(min_derivative), int(inverse), pf.dtype, _stream())
@@ -434,6 +437,7 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
     with torch.cuda.device(x.device):
         code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * (3 * pf.K - 1), B), launch)
         _check(code, 'nf_made_rqs_fwd')
+    out._nf_max = y_max                 # (None outside the split-operand whole-layer launches)
     return out, logabsdet, bins
 
 

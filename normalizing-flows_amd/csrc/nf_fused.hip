@@ -756,9 +756,22 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
         for (int w = 0; w < XT / 64; ++w) s += ldp[w * XM + tid];
         if (m0 + tid < g.M) g.partial[(int64_t)tn * g.M + m0 + tid] = s;
     }
+    float ymax = 0.f;
     for (int i = tid; i < XM * fpt; i += XT) {
         const int r = i / fpt, f = i - r * fpt;
-        if (m0 + r < g.M && f < fv) g.y[(m0 + r) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = xs[i];
+        if (m0 + r < g.M && f < fv) {
+            const float v = xs[i];
+            g.y[(m0 + r) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = v;
+            const float a = fabsf(v);
+            ymax = fmaxf(ymax, a < INFINITY ? a : 0.f);
+        }
+    }
+    if (g.out_max) {                                 // max |y| for the next layer's operand scale
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+        // (read first: after the first few workgroups almost nobody holds a larger value, and tens of thousands
+        //  of same-address atomics per launch would queue up in L2)
+        if (lane == 0 && __float_as_uint(ymax) > __builtin_nontemporal_load(g.out_max)) atomicMax(g.out_max, __float_as_uint(ymax));
     }
 }
 
@@ -806,7 +819,7 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
     if (g.out_max) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-        if (lane == 0) atomicMax(g.out_max, __float_as_uint(vmax));
+        if (lane == 0 && __float_as_uint(vmax) > __builtin_nontemporal_load(g.out_max)) atomicMax(g.out_max, __float_as_uint(vmax));
     }
 }
 
@@ -1082,10 +1095,15 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
                           int accumulate, int32_t* bin_idx, float* workspace, size_t workspace_bytes, int64_t B, int in,
                           int features, int K, int tails, double tail_bound, double min_bin_width,
                           double min_bin_height, double min_derivative, int inverse, int dtype, int tile_begin,
-                          int tile_count, int feat_limit, int reduce, const unsigned* h_max, void* stream) {
+                          int tile_count, int feat_limit, int reduce, const unsigned* h_max, unsigned* y_max,
+                          void* stream) {
     if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
     if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && !split_terms(dtype)) return NF_ERR_DTYPE;
+    if (y_max) {
+        hipError_t me = hipMemsetAsync(y_max, 0, sizeof(unsigned), (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+    }
     if (B == 0) return NF_OK;
     if (!h || !packed_w || !ktab || !bias_packed || !x || !y || !logabsdet || !workspace) return NF_ERR_NULL;
     if (h_row_stride < in || x_row_stride < row_width || y_row_stride < row_width) return NF_ERR_LAYOUT;
@@ -1096,7 +1114,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     FusedArgs g;
     g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
-    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = nullptr;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
@@ -1150,7 +1168,7 @@ extern "C" int nf_made_rqs_fwd_tiles(const float* h, int64_t h_row_stride, const
     return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr,
                           features, logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
                           tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, tile_begin,
-                          tile_count, feat_limit, reduce, nullptr, stream);
+                          tile_count, feat_limit, reduce, nullptr, nullptr, stream);
 }
 
 extern "C" int nf_coupling_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
@@ -1165,20 +1183,20 @@ extern "C" int nf_coupling_rqs_fwd(const float* h, int64_t h_row_stride, const v
     return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, feat_index,
                           row_width, logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K,
                           tails, tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
-                          nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, stream);
+                          nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, nullptr, stream);
 }
 
 // nf_made_rqs_fwd with the producer's max |h| slot (split-operand dtypes: skips the max pre-pass)
 extern "C" int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h_max, const void* packed_w,
                                     const int32_t* ktab, const float* bias_packed, const float* x, int64_t x_row_stride,
-                                    float* y, int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                                    float* y, int64_t y_row_stride, uint32_t* y_max, float* logabsdet, int accumulate, int32_t* bin_idx,
                                     float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
                                     int tails, double tail_bound, double min_bin_width, double min_bin_height,
                                     double min_derivative, int inverse, int dtype, void* stream) {
     return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr,
                           features, logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
                           tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
-                          nf_made_rqs_tiles(features, K, tails), features, 1, (const unsigned*)h_max, stream);
+                          nf_made_rqs_tiles(features, K, tails), features, 1, (const unsigned*)h_max, (unsigned*)y_max, stream);
 }
 
 extern "C" int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,

@@ -79,10 +79,23 @@ class AutoregressiveTransform(nn.Module):
         B = inputs.shape[0]
         outputs = torch.empty_like(inputs)
         logabsdet = torch.empty(B, dtype=inputs.dtype, device=inputs.device)
-        for s in range(0, max(B, 1), CHUNK_ROWS):
+        if B <= CHUNK_ROWS:
+            # one launch group: no slicing, so the tensors keep what the kernels attached to them (the
+            # split-operand kernels hand max |y| to the next layer's first GEMM that way)
+            self._transform_rows(inputs, inputs, context, outputs, logabsdet, inverse=False)
+            return outputs, logabsdet
+        # per launch group; what the kernels attach to a group's output (max |y| of the split-operand kernels)
+        # is kept per group on the full tensor and re-attached to the next layer's slices
+        have = getattr(inputs, '_nf_chunk_max', None) or {}
+        keep = {}
+        for s in range(0, B, CHUNK_ROWS):
             e = min(B, s + CHUNK_ROWS)
             ctx = None if context is None else context[s:e]
-            self._transform_rows(inputs[s:e], inputs[s:e], ctx, outputs[s:e], logabsdet[s:e], inverse=False)
+            xin, yout = inputs[s:e], outputs[s:e]
+            xin._nf_max = have.get((s, e))
+            self._transform_rows(xin, xin, ctx, yout, logabsdet[s:e], inverse=False)
+            keep[(s, e)] = getattr(yout, '_nf_max', None)
+        outputs._nf_chunk_max = keep
         return outputs, logabsdet
 
     def _forward_autograd(self, inputs, context):
