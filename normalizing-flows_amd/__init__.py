@@ -7,7 +7,8 @@ from .resnet import ResidualNet, ResidualBlock
 from .transforms import CompositeTransform, AutoregressiveTransform, MaskedAffineAutoregressiveTransform, \
     MaskedPiecewiseRationalQuadraticAutoregressiveTransform, CouplingTransform, AffineCouplingTransform, \
     PiecewiseRationalQuadraticCouplingTransform
-from . import parallel
+from . import parallel, metrics
+from .checkpoint import save_checkpoint, load_checkpoint
 from .flows import MaskedAutoregressiveFlow, SimpleMADE, SimpleMaskedLinear
 from .distributions import Distribution, StandardNormal, BaseNeuralSplineFlow, Flow
 

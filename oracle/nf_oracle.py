@@ -468,3 +468,21 @@ def seeded_made_state_dict(features, hidden_features, output_multiplier, num_blo
         sd[prefix + name + '.mask'] = m.to(dtype)
         sd[prefix + name + '.degrees'] = deg
     return sd
+
+
+def compute_ess(logp, logq):
+    """helper_functions.py:36-40: exp(2 lse(logw) - lse(2 logw)) / N."""
+    logw = logp - logq
+    log_ess = 2 * torch.logsumexp(logw, dim=0) - torch.logsumexp(2 * logw, dim=0)
+    return torch.exp(log_ess) / len(logw)
+
+
+def forward_kl(logp, logq):
+    """model.py:126-130."""
+    return (logp - logq).mean()
+
+
+def reverse_kl(logq, logp):
+    """model.py:132-136."""
+    return (logq - logp).mean()
+

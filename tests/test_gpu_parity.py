@@ -677,3 +677,32 @@ def test_short_training_run_lowers_the_loss(nf):
     fl = flow._transform._transforms[0].autoregressive_net.final_layer
     moved = (fl.weight.detach() - w0) != 0
     assert not moved[fl.mask == 0].any() and moved[fl.mask == 1].any()
+
+
+def test_flow_metrics_end_to_end(nf):
+    """ESS / KL / JS of a small flow against a shifted Gaussian target (reference model.py:110-142): the
+    GPU pipeline (sample -> log_prob both ways -> reductions) against the same formulas on the CPU oracle."""
+    torch.manual_seed(4)
+    D, H, K = 6, 32, 4
+
+    class Target:
+        def sample_n(self, n):
+            return torch.randn(n, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(8)) + 0.1
+
+        def log_prob(self, x):
+            return -0.5 * ((x - 0.1) ** 2).sum(1) - 0.5 * D * np.log(2 * np.pi)
+
+    layers = [nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, num_bins=K, tails='linear',
+                                                                         tail_bound=4.) for _ in range(2)]
+    flow = nf.BaseNeuralSplineFlow(nf.CompositeTransform(layers), nf.StandardNormal([D])).cuda().eval()
+    m = nf.metrics.flow_metrics(flow, Target(), 512)
+    assert 0.0 < m['ess'] <= 1.0 and 0.0 < m['target_ess'] <= 1.0
+    assert abs(m['jensen_shannon'] - 0.5 * (m['forward_kl'] + m['reverse_kl'])) < 1e-12
+    # the forward-KL leg against the oracle on the same target samples
+    y = Target().sample_n(512)
+    sds = [O.split_state_dict({k: v.detach().cpu() for k, v in flow._transform.state_dict().items()}, j)
+           for j in range(2)]
+    logq = O.flow_log_prob([lambda v, s=s: O.rq_autoregressive_forward(s, v, K, 4.0) for s in sds], y.cpu())
+    want = O.forward_kl(Target().log_prob(y).cpu().double(), logq.double()).item()
+    assert abs(m['forward_kl'] - want) < 1e-4 * max(1.0, abs(want))
+
