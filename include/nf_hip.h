@@ -106,6 +106,23 @@ int nf_rqs_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index,
                double min_bin_width, double min_bin_height, double min_derivative,
                int inverse, void* stream);
 
+/* ---- linear and quadratic spline families (same launch shape and argument meaning as
+ *      nf_rqs_fwd) --------------------------------------------------------------------------------- */
+
+/* Piecewise-linear CDF on K equal bins (replaces splines/linear.py:35-94 `linear_spline`, and with tails != 0
+ * :9-33 `unconstrained_linear_spline`): params[b, d*K + k] = unnormalised pdf.  tails == 0: x in [0, 1]. */
+int nf_linear_spline_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index, const float* params,
+                         int64_t param_row_stride, float* y, int64_t y_row_stride, float* logabsdet, int accumulate,
+                         int32_t* bin_idx, int64_t B, int D, int K, int tails, double tail_bound, int inverse,
+                         void* stream);
+/* Piecewise-quadratic CDF (replaces splines/quadratic.py:48-135 `quadratic_spline` / :11-46
+ * `unconstrained_quadratic_spline`): per element K unnormalised widths then K+1 (tails == 0) or K-1
+ * (linear tails) unnormalised heights.  NF_ERR_BINS as in nf_rqs_fwd. */
+int nf_quadratic_spline_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index, const float* params,
+                            int64_t param_row_stride, float* y, int64_t y_row_stride, float* logabsdet,
+                            int accumulate, int32_t* bin_idx, int64_t B, int D, int K, int tails, double tail_bound,
+                            double min_bin_width, double min_bin_height, int inverse, void* stream);
+
 /* ---- final MADE layer fused with the spline: `params` never reaches HBM ---------------------------
  *      (replaces made.py:358 `self.final_layer(outputs)` + transforms.py:819-860 `_elementwise` +
  *       rational_quadratic.py:13-149 in one launch; the forward AND the per-pass inverse of the

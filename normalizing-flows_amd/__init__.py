@@ -5,7 +5,8 @@ from .made import MADE, MaskedLinear, DenseLinear, MaskedResidualBlock, MaskedFe
     set_matmul_dtype, get_matmul_dtype
 from .resnet import ResidualNet, ResidualBlock
 from .transforms import CompositeTransform, AutoregressiveTransform, MaskedAffineAutoregressiveTransform, \
-    MaskedPiecewiseRationalQuadraticAutoregressiveTransform, CouplingTransform, AffineCouplingTransform, \
+    MaskedPiecewiseRationalQuadraticAutoregressiveTransform, MaskedPiecewiseLinearAutoregressiveTransform, \
+    MaskedPiecewiseQuadraticAutoregressiveTransform, CouplingTransform, AffineCouplingTransform, \
     PiecewiseRationalQuadraticCouplingTransform
 from . import parallel, metrics
 from .checkpoint import save_checkpoint, load_checkpoint

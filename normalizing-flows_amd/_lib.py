@@ -48,6 +48,13 @@ _SIGNATURES = {
                               _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64,
                               _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
                               _c.c_double, _c.c_int, _c.c_void_p]),
+    'nf_linear_spline_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                                        _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
+                                        _c.c_int, _c.c_double, _c.c_int, _c.c_void_p]),
+    'nf_quadratic_spline_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                                           _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int,
+                                           _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
+                                           _c.c_void_p]),
     'nf_affine_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
                                  _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_int,
                                  _c.c_int, _c.c_void_p]),
@@ -524,6 +531,51 @@ def rqs(x, params, num_bins, tails, tail_bound, inverse=False, pre_div=1.0, feat
     with torch.cuda.device(x.device):
         code = launch() if _timer is None else _timer.record(('rqs', D, int(num_bins), B), launch)
         _check(code, 'nf_rqs_fwd')
+    return out, logabsdet, bins
+
+
+def _family_call(x, params, out, logabsdet, accumulate, want_bins, num_features):
+    _dev(x, 'inputs')
+    _dev(params, 'params')
+    B = x.shape[0]
+    D = int(num_features if num_features is not None else x.shape[1])
+    xp, xs = _rows(x, 'inputs')
+    pp, ps = _rows(params, 'params')
+    if out is None:
+        out = torch.empty_like(x)
+    yp, ys = _rows(out, 'outputs')
+    if logabsdet is None:
+        logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        accumulate = False
+    bins = torch.empty((B, D), dtype=torch.int32, device=x.device) if want_bins else None
+    return B, D, xp, xs, pp, ps, out, yp, ys, logabsdet, accumulate, bins
+
+
+def linear_spline(x, params, num_bins, tails=None, tail_bound=1.0, inverse=False, feat_index=None, out=None,
+                  logabsdet=None, accumulate=False, want_bins=False, num_features=None):
+    """Piecewise-linear CDF spline: params [B, D*K] unnormalised pdf -> (y, logabsdet[B], bins or None)."""
+    lib = load()
+    B, D, xp, xs, pp, ps, out, yp, ys, logabsdet, accumulate, bins = _family_call(
+        x, params, out, logabsdet, accumulate, want_bins, num_features)
+    with torch.cuda.device(x.device):
+        _check(lib.nf_linear_spline_fwd(xp, xs, _ptr(feat_index), pp, ps, yp, ys, logabsdet.data_ptr(), int(accumulate),
+                                        _ptr(bins), B, D, int(num_bins), 1 if tails == 'linear' else 0,
+                                        float(tail_bound), int(inverse), _stream()), 'nf_linear_spline_fwd')
+    return out, logabsdet, bins
+
+
+def quadratic_spline(x, params, num_bins, tails=None, tail_bound=1.0, inverse=False, feat_index=None, out=None,
+                     logabsdet=None, accumulate=False, min_bin_width=1e-3, min_bin_height=1e-3, want_bins=False,
+                     num_features=None):
+    """Piecewise-quadratic CDF spline: params [B, D*(2K+1)] (or 2K-1 with linear tails)."""
+    lib = load()
+    B, D, xp, xs, pp, ps, out, yp, ys, logabsdet, accumulate, bins = _family_call(
+        x, params, out, logabsdet, accumulate, want_bins, num_features)
+    with torch.cuda.device(x.device):
+        _check(lib.nf_quadratic_spline_fwd(xp, xs, _ptr(feat_index), pp, ps, yp, ys, logabsdet.data_ptr(),
+                                           int(accumulate), _ptr(bins), B, D, int(num_bins),
+                                           1 if tails == 'linear' else 0, float(tail_bound), float(min_bin_width),
+                                           float(min_bin_height), int(inverse), _stream()), 'nf_quadratic_spline_fwd')
     return out, logabsdet, bins
 
 

@@ -17,6 +17,7 @@
 // the reference as closely as a different expf allows.
 #include "nf_common.h"
 #include "nf_rqs_eval.h"
+#include "nf_spline_families.h"
 
 namespace {
 
@@ -55,7 +56,8 @@ __device__ __forceinline__ float4 load_vec(const float* __restrict__ params, int
     return v;
 }
 
-template <int KT, bool INV, int MAXV>
+// FAM: 0 rational-quadratic, 1 linear, 2 quadratic spline (nf_spline_families.h); the staging is the same
+template <int KT, bool INV, int MAXV, int FAM = 0>
 __global__ __launch_bounds__(kThreads) void rqs_kernel(const RqsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(kThreads) void rqs_kernel(const RqsArgs a) {
             const float xv = a.x[(row0 + r) * a.x_stride + col];
             float yv, ld;
             int bin;
-            rqs_eval<KT, INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
+            if (FAM == 1) lin_eval<INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
+            else if (FAM == 2) quad_eval<INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
+            else rqs_eval<KT, INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
             a.y[(row0 + r) * a.y_stride + col] = yv;
             if (a.bins) a.bins[(row0 + r) * (int64_t)D + d] = bin;
             ldbuf[e] = ld;
@@ -301,7 +305,67 @@ int launch_rqs(const RqsArgs& a, int grid, size_t lds, hipStream_t s) {
     }
 }
 
+template <bool INV, int FAM>
+int launch_family(const RqsArgs& a, int grid, size_t lds, hipStream_t s) {
+    const int nv = (kThreads * a.c.P + 4 + 3) / 4;
+    const int per = (nv + kThreads - 1) / kThreads;
+    if (per <= 6) hipLaunchKernelGGL((rqs_kernel<0, INV, 6, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
+    else if (per <= 12) hipLaunchKernelGGL((rqs_kernel<0, INV, 12, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
+    else if (per <= 25) hipLaunchKernelGGL((rqs_kernel<0, INV, 25, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
+    else return NF_ERR_SHAPE;
+    return nf_launch_status();
+}
+
+// shared body of the linear / quadratic spline entry points: P parameters per element
+template <int FAM>
+int family_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index, const float* params,
+               int64_t param_row_stride, float* y, int64_t y_row_stride, float* logabsdet, int accumulate,
+               int32_t* bin_idx, int64_t B, int D, int K, int P, int tails, double tail_bound, double min_w,
+               double min_h, int inverse, void* stream) {
+    if (B == 0) return NF_OK;
+    if (!x || !params || !y || !logabsdet) return NF_ERR_NULL;
+    if (param_row_stride != (int64_t)D * P) return NF_ERR_LAYOUT;
+    if (x_row_stride < D || y_row_stride < D) return NF_ERR_LAYOUT;
+    RqsArgs a;
+    a.x = x; a.x_stride = x_row_stride; a.feat = feat_index;
+    a.params = params; a.n_param_floats = B * (int64_t)D * P;
+    a.y = y; a.y_stride = y_row_stride; a.lad = logabsdet; a.accumulate = accumulate; a.bins = bin_idx;
+    a.B = B; a.D = D;
+    a.c = nf_make_rqs_const(K, tails, tail_bound, min_w, min_h, 1e-3, 1.0);
+    a.c.P = P;
+    a.rows_per_block = pick_rows_per_block(D, B);
+    a.vec_ok = ((uintptr_t)params & 15) == 0;
+    const int stage_floats = (kThreads * P + 4 + 3) & ~3;
+    size_t lds = sizeof(float) * ((size_t)stage_floats + (size_t)a.rows_per_block * D);
+    if (lds > 160 * 1024) return NF_ERR_SHAPE;
+    const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
+    if (grid > 0x7fffffff) return NF_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    return inverse ? launch_family<true, FAM>(a, (int)grid, lds, s) : launch_family<false, FAM>(a, (int)grid, lds, s);
+}
+
 }  // namespace
+
+extern "C" int nf_linear_spline_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index,
+                                    const float* params, int64_t param_row_stride, float* y, int64_t y_row_stride,
+                                    float* logabsdet, int accumulate, int32_t* bin_idx, int64_t B, int D, int K,
+                                    int tails, double tail_bound, int inverse, void* stream) {
+    if (B < 0 || D <= 0 || K <= 0 || K > 64) return NF_ERR_SHAPE;
+    return family_fwd<1>(x, x_row_stride, feat_index, params, param_row_stride, y, y_row_stride, logabsdet, accumulate,
+                         bin_idx, B, D, K, K, tails, tail_bound, 0.0, 0.0, inverse, stream);
+}
+
+extern "C" int nf_quadratic_spline_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index,
+                                       const float* params, int64_t param_row_stride, float* y, int64_t y_row_stride,
+                                       float* logabsdet, int accumulate, int32_t* bin_idx, int64_t B, int D, int K,
+                                       int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                                       int inverse, void* stream) {
+    if (B < 0 || D <= 0 || K < 2 || K > 32) return NF_ERR_SHAPE;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+    return family_fwd<2>(x, x_row_stride, feat_index, params, param_row_stride, y, y_row_stride, logabsdet, accumulate,
+                         bin_idx, B, D, K, tails ? 2 * K - 1 : 2 * K + 1, tails, tail_bound, min_bin_width,
+                         min_bin_height, inverse, stream);
+}
 
 extern "C" int nf_rqs_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index,
                           const float* params, int64_t param_row_stride, double pre_div,

@@ -281,6 +281,68 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         return self._transform_rows(inputs, inputs, context, torch.empty_like(inputs), None, False, want_bins=True)
 
 
+class MaskedPiecewiseLinearAutoregressiveTransform(AutoregressiveTransform):
+    """Piecewise-linear CDF spline on [0, 1] with MADE-produced bin masses (reference transforms.py:568-616;
+    its `splines.linear_spline` is read as models/splines/linear.py:35-94)."""
+
+    def __init__(self, num_bins, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu, dropout_probability=0.,
+                 use_batch_norm=False):
+        self.num_bins = num_bins
+        self.features = features
+        made = made_module.MADE(
+            features=features, hidden_features=hidden_features, context_features=context_features,
+            num_blocks=num_blocks, output_multiplier=self._output_dim_multiplier(),
+            use_residual_blocks=use_residual_blocks, random_mask=random_mask, activation=activation,
+            dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        return self.num_bins
+
+    def _elementwise(self, inputs, params, outputs, logabsdet, inverse):
+        _lib.linear_spline(inputs, params, self.num_bins, tails=None, inverse=inverse, out=outputs,
+                           logabsdet=logabsdet)
+
+
+class MaskedPiecewiseQuadraticAutoregressiveTransform(AutoregressiveTransform):
+    """Piecewise-quadratic CDF spline with MADE-produced widths / knot heights (reference transforms.py:618-705;
+    `tails=None` -> models/splines/quadratic.py:48-135 on [0, 1], 'linear' -> :11-46).  The reference's
+    division by sqrt(hidden_features) never fires on this path: MADE has no such attribute."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_bins=10, num_blocks=2, tails=None,
+                 tail_bound=1., use_residual_blocks=True, random_mask=False, activation=F.relu,
+                 dropout_probability=0., use_batch_norm=False, min_bin_width=DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=DEFAULT_MIN_BIN_HEIGHT, min_derivative=DEFAULT_MIN_DERIVATIVE):
+        if tails not in (None, 'linear'):
+            raise ValueError
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.tail_bound = tail_bound
+        self.features = features
+        made = made_module.MADE(
+            features=features, hidden_features=hidden_features, context_features=context_features,
+            num_blocks=num_blocks, output_multiplier=self._output_dim_multiplier(),
+            use_residual_blocks=use_residual_blocks, random_mask=random_mask, activation=activation,
+            dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        return self.num_bins * 2 - 1 if self.tails == 'linear' else self.num_bins * 2 + 1
+
+    def _elementwise(self, inputs, params, outputs, logabsdet, inverse):
+        if self.min_bin_width * self.num_bins > 1.0:
+            raise ValueError('Minimal bin width too large for the number of bins')
+        if self.min_bin_height * self.num_bins > 1.0:
+            raise ValueError('Minimal bin height too large for the number of bins')
+        _lib.quadratic_spline(inputs, params, self.num_bins, tails=self.tails, tail_bound=self.tail_bound,
+                              inverse=inverse, out=outputs, logabsdet=logabsdet, min_bin_width=self.min_bin_width,
+                              min_bin_height=self.min_bin_height)
+
+
 # ------------------------------------------------------------------------------------ coupling
 class CouplingTransform(nn.Module):
     """Splits features by a binary mask; the identity half conditions the transform of the other

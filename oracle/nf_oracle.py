@@ -486,3 +486,137 @@ def reverse_kl(logq, logp):
     """model.py:132-136."""
     return (logq - logp).mean()
 
+
+# --------------------------------------------------------------------------- linear / quadratic splines
+def linear_spline(inputs, unnormalized_pdf, inverse=False, left=0., right=1., bottom=0., top=1.,
+                  return_bins=False):
+    """Piecewise-linear CDF on K equal bins (models/splines/linear.py:35-94).  Forward: bin = floor(x K);
+    inverse: search over the cdf (whose last entry the search raises by 1e-6 in place, :52 + the slopes
+    of :58-60 are then built from the raised value)."""
+    inputs = (inputs - bottom) / (top - bottom) if inverse else (inputs - left) / (right - left)
+    nb = unnormalized_pdf.size(-1)
+    pdf = F.softmax(unnormalized_pdf, dim=-1)
+    cdf = torch.cumsum(pdf, dim=-1)
+    cdf[..., -1] = 1.
+    cdf = F.pad(cdf, pad=(1, 0), mode='constant', value=0.0)
+    if inverse:
+        idx = searchsorted(cdf, inputs)
+        edges = torch.linspace(0, 1, nb + 1).view([1] * inputs.dim() + [-1]).expand(*inputs.shape, -1)
+        slopes = (cdf[..., 1:] - cdf[..., :-1]) / (edges[..., 1:] - edges[..., :-1])
+        offsets = cdf[..., 1:] - slopes * edges[..., 1:]
+        sel = idx.unsqueeze(-1)
+        s_in = slopes.gather(-1, sel)[..., 0]
+        o_in = offsets.gather(-1, sel)[..., 0]
+        outputs = torch.clamp((inputs - o_in) / s_in, 0, 1)
+        lad = -torch.log(s_in)
+    else:
+        pos = inputs * nb
+        idx = torch.floor(pos).long()
+        idx[idx >= nb] = nb - 1
+        alpha = pos - idx.float()
+        p_in = pdf.gather(-1, idx[..., None])[..., 0]
+        outputs = cdf.gather(-1, idx[..., None])[..., 0]
+        outputs += alpha * p_in
+        outputs = torch.clamp(outputs, 0, 1)
+        lad = torch.log(p_in) - np.log(1.0 / nb)
+    if inverse:
+        outputs = outputs * (right - left) + left
+        lad = lad - math.log(top - bottom) + math.log(right - left)
+    else:
+        outputs = outputs * (top - bottom) + bottom
+        lad = lad + math.log(top - bottom) - math.log(right - left)
+    if return_bins:
+        return outputs, lad, idx
+    return outputs, lad
+
+
+def unconstrained_linear_spline(inputs, unnormalized_pdf, inverse=False, tail_bound=1., return_bins=False):
+    """Identity outside [-T, T] (models/splines/linear.py:9-33)."""
+    inside = (inputs >= -tail_bound) & (inputs <= tail_bound)
+    outputs = torch.zeros_like(inputs)
+    lad = torch.zeros_like(inputs)
+    outputs[~inside] = inputs[~inside]
+    res = linear_spline(inputs[inside], unnormalized_pdf[inside, :], inverse=inverse, left=-tail_bound,
+                        right=tail_bound, bottom=-tail_bound, top=tail_bound, return_bins=return_bins)
+    outputs[inside], lad[inside] = res[0], res[1]
+    if return_bins:
+        bins = torch.full(inputs.shape, -1, dtype=torch.int64)
+        bins[inside] = res[2]
+        return outputs, lad, bins
+    return outputs, lad
+
+
+def quadratic_spline(inputs, uw, uh, inverse=False, left=0., right=1., bottom=0., top=1.,
+                     min_bin_width=1e-3, min_bin_height=1e-3, return_bins=False):
+    """Piecewise-quadratic CDF = integral of a piecewise-linear density (models/splines/quadratic.py:48-135).
+    `uh` has K+1 entries, or K-1 with the two boundary heights chosen so that they normalise to 1 (:73-84)."""
+    inputs = (inputs - bottom) / (top - bottom) if inverse else (inputs - left) / (right - left)
+    nb = uw.shape[-1]
+    if min_bin_width * nb > 1.0:
+        raise ValueError('Minimal bin width too large for the number of bins')
+    if min_bin_height * nb > 1.0:
+        raise ValueError('Minimal bin height too large for the number of bins')
+    widths = F.softmax(uw, dim=-1)
+    widths = min_bin_width + (1 - min_bin_width * nb) * widths
+    he = torch.exp(uh)
+    if he.shape[-1] == nb - 1:
+        first = 0.5 * widths[..., 0]
+        last = 0.5 * widths[..., -1]
+        num = (0.5 * first * he[..., 0] + 0.5 * last * he[..., -1]
+               + torch.sum(((he[..., :-1] + he[..., 1:]) / 2) * widths[..., 1:-1], dim=-1))
+        const = (num / (1 - 0.5 * first - 0.5 * last))[..., None]
+        he = torch.cat([const, he, const], dim=-1)
+    area = torch.sum(((he[..., :-1] + he[..., 1:]) / 2) * widths, dim=-1)[..., None]
+    heights = he / area
+    heights = min_bin_height + (1 - min_bin_height) * heights
+    left_cdf = torch.cumsum(((heights[..., :-1] + heights[..., 1:]) / 2) * widths, dim=-1)
+    left_cdf[..., -1] = 1.
+    left_cdf = F.pad(left_cdf, pad=(1, 0), mode='constant', value=0.0)
+    locs = torch.cumsum(widths, dim=-1)
+    locs[..., -1] = 1.
+    locs = F.pad(locs, pad=(1, 0), mode='constant', value=0.0)
+    idx = (searchsorted(left_cdf, inputs) if inverse else searchsorted(locs, inputs))[..., None]
+    loc_in = locs.gather(-1, idx)[..., 0]
+    w_in = widths.gather(-1, idx)[..., 0]
+    c = left_cdf.gather(-1, idx)[..., 0]
+    hl = heights.gather(-1, idx)[..., 0]
+    hr = heights.gather(-1, idx + 1)[..., 0]
+    a = 0.5 * (hr - hl) * w_in
+    b = hl * w_in
+    if inverse:
+        c_ = c - inputs
+        alpha = (-b + torch.sqrt(b.pow(2) - 4 * a * c_)) / (2 * a)
+        outputs = torch.clamp(alpha * w_in + loc_in, 0, 1)
+        lad = -torch.log(alpha * (hr - hl) + hl)
+    else:
+        alpha = (inputs - loc_in) / w_in
+        outputs = torch.clamp(a * alpha.pow(2) + b * alpha + c, 0, 1)
+        lad = torch.log(alpha * (hr - hl) + hl)
+    if inverse:
+        outputs = outputs * (right - left) + left
+        lad = lad - math.log(top - bottom) + math.log(right - left)
+    else:
+        outputs = outputs * (top - bottom) + bottom
+        lad = lad + math.log(top - bottom) - math.log(right - left)
+    if return_bins:
+        return outputs, lad, idx[..., 0]
+    return outputs, lad
+
+
+def unconstrained_quadratic_spline(inputs, uw, uh, inverse=False, tail_bound=1., min_bin_width=1e-3,
+                                   min_bin_height=1e-3, return_bins=False):
+    """Identity outside [-T, T]; K-1 heights (models/splines/quadratic.py:11-46)."""
+    inside = (inputs >= -tail_bound) & (inputs <= tail_bound)
+    outputs = torch.zeros_like(inputs)
+    lad = torch.zeros_like(inputs)
+    outputs[~inside] = inputs[~inside]
+    assert uh.shape[-1] == uw.shape[-1] - 1
+    res = quadratic_spline(inputs[inside], uw[inside, :], uh[inside, :], inverse=inverse, left=-tail_bound,
+                           right=tail_bound, bottom=-tail_bound, top=tail_bound, min_bin_width=min_bin_width,
+                           min_bin_height=min_bin_height, return_bins=return_bins)
+    outputs[inside], lad[inside] = res[0], res[1]
+    if return_bins:
+        bins = torch.full(inputs.shape, -1, dtype=torch.int64)
+        bins[inside] = res[2]
+        return outputs, lad, bins
+    return outputs, lad

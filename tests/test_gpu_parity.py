@@ -706,3 +706,81 @@ def test_flow_metrics_end_to_end(nf):
     want = O.forward_kl(Target().log_prob(y).cpu().double(), logq.double()).item()
     assert abs(m['forward_kl'] - want) < 1e-4 * max(1.0, abs(want))
 
+
+# ------------------------------------------------------------------------------- linear / quadratic splines
+@pytest.mark.parametrize('tag', ['K8_T3', 'K5_unit', 'K32_T50'])
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_linear_spline_golden(nf, tag, direction):
+    fx = load_golden('linspline_' + tag)
+    K, Tb, tails = int(fx['num_bins']), float(fx['tail_bound']), 'linear' if int(fx['tails']) else None
+    x = dev(fx[direction + '_x']).reshape(-1, 1)
+    y, ld, bins = nf._lib.linear_spline(x, dev(fx['params']), K, tails=tails, tail_bound=Tb,
+                                        inverse=direction == 'inv', want_bins=True)
+    assert_close(y.reshape(-1), fx[direction + '_y64'], fx[direction + '_y32'])
+    assert_close(ld, fx[direction + '_ld64'], fx[direction + '_ld32'])
+    assert int(bins.max()) <= K - 1
+
+
+@pytest.mark.parametrize('tag', ['K8_T3', 'K6_unit', 'K16_T10'])
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_quadratic_spline_golden(nf, tag, direction):
+    fx = load_golden('quadspline_' + tag)
+    K, Tb, tails = int(fx['num_bins']), float(fx['tail_bound']), 'linear' if int(fx['tails']) else None
+    x = dev(fx[direction + '_x']).reshape(-1, 1)
+    y, ld, bins = nf._lib.quadratic_spline(x, dev(fx['params']), K, tails=tails, tail_bound=Tb,
+                                           inverse=direction == 'inv', want_bins=True)
+    # mult=16: the inverse's root is ill-conditioned near flat densities - perturbing the parameters of the worst
+    # element of K8_T3 by one fp32 ulp moves the REFERENCE's own fp32 logdet by +-4e-4 (its single run happens to
+    # land 5e-6 from the fp64 value), so 4x the reference's observed distance is not a bound here
+    assert_close(y.reshape(-1), fx[direction + '_y64'], fx[direction + '_y32'], mult=16.0)
+    assert_close(ld, fx[direction + '_ld64'], fx[direction + '_ld32'], mult=16.0)
+    # bin indices: bit-exact wherever the reference's own fp32 and fp64 searches agree
+    b32, b64 = T(fx[direction + '_bins32']).long(), T(fx[direction + '_bins64']).long()
+    agree = b32 == b64
+    assert (bins.cpu().reshape(-1).long()[agree] == b64[agree]).float().mean().item() > 0.999
+    with pytest.raises(ValueError):                    # the reference's error (quadratic.py:64-67)
+        nf._lib.quadratic_spline(x, dev(fx['params']), K, tails=tails, min_bin_width=0.5)
+
+
+@pytest.mark.parametrize('family', ['linear', 'quadratic', 'quadratic_tails'])
+def test_spline_family_autoregressive_transforms(nf, family):
+    """MaskedPiecewise{Linear,Quadratic}AutoregressiveTransform: forward and the D-pass inverse against the
+    oracle's MADE + spline (weights through the state_dict, reference key names), ragged batch."""
+    torch.manual_seed(12)
+    D, H, K, B = 9, 32, 6, 130
+    if family == 'linear':
+        t = nf.MaskedPiecewiseLinearAutoregressiveTransform(K, D, H)
+        mult = K
+        spline = lambda v, p, inv: O.linear_spline(v, p, inverse=inv)
+        x = torch.rand(B, D) * 0.98 + 0.01
+    elif family == 'quadratic':
+        t = nf.MaskedPiecewiseQuadraticAutoregressiveTransform(D, H, num_bins=K)
+        mult = 2 * K + 1
+        spline = lambda v, p, inv: O.quadratic_spline(v, p[..., :K], p[..., K:], inverse=inv)
+        x = torch.rand(B, D) * 0.98 + 0.01
+    else:
+        t = nf.MaskedPiecewiseQuadraticAutoregressiveTransform(D, H, num_bins=K, tails='linear', tail_bound=2.0)
+        mult = 2 * K - 1
+        spline = lambda v, p, inv: O.unconstrained_quadratic_spline(v, p[..., :K], p[..., K:], inverse=inv, tail_bound=2.0)
+        x = torch.randn(B, D)
+    with torch.no_grad():
+        for p_ in t.parameters():
+            p_.mul_(2.0)
+    sd = {k: v.detach().clone() for k, v in t.state_dict().items()}
+    t = t.cuda().eval()
+
+    def ref_forward(v, dt):
+        sdd = {k: (w.to(dt) if w.is_floating_point() else w) for k, w in sd.items()}
+        params = O.made_forward(sdd, v.to(dt), 'autoregressive_net.').view(v.shape[0], D, mult)
+        y, ld = spline(v.to(dt), params, False)
+        return y, O.sum_except_batch(ld)
+
+    with torch.no_grad():
+        y, ld = t(x.cuda())
+        xi, ldi = t.inverse(y)
+    y64, ld64 = ref_forward(x, torch.float64)
+    y32, ld32 = ref_forward(x, torch.float32)
+    assert_close(y, y64, y32)
+    assert_close(ld, ld64, ld32)
+    assert (xi.cpu() - x).abs().max().item() < 1e-4 and (ldi + ld).abs().max().item() < 1e-3
+

@@ -202,3 +202,38 @@ def test_maf(D):
         w, b, m, rev = layer(j)
         r, lj = O.maf_reverse(w, b, m, r, rev)
         assert rel_err(r, fx['l%d/rev_z' % j]) < 1e-13 and rel_err(lj, fx['l%d/rev_logJ' % j]) < 1e-13
+
+
+# ---------------------------------------------------------------- linear / quadratic spline families
+@pytest.mark.parametrize('tag', ['K8_T3', 'K5_unit', 'K32_T50'])
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_linear_spline_family(tag, direction):
+    fx = load_golden('linspline_' + tag)
+    Tb, tails = float(fx['tail_bound']), bool(int(fx['tails']))
+    u, x, inv = T(fx['params']), T(fx[direction + '_x']), direction == 'inv'
+    for dt, sfx in ((torch.float32, '32'), (torch.float64, '64')):
+        if tails:
+            y, ld = O.unconstrained_linear_spline(x.to(dt), u.to(dt).clone(), inverse=inv, tail_bound=Tb)
+        else:
+            y, ld = O.linear_spline(x.to(dt), u.to(dt).clone(), inverse=inv)
+        assert torch.equal(y, T(fx[direction + '_y' + sfx]))              # same op sequence => same bits
+        assert torch.equal(ld, T(fx[direction + '_ld' + sfx]))
+
+
+@pytest.mark.parametrize('tag', ['K8_T3', 'K6_unit', 'K16_T10'])
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_quadratic_spline_family(tag, direction):
+    fx = load_golden('quadspline_' + tag)
+    K, Tb, tails = int(fx['num_bins']), float(fx['tail_bound']), bool(int(fx['tails']))
+    p, x, inv = T(fx['params']), T(fx[direction + '_x']), direction == 'inv'
+    for dt, sfx in ((torch.float32, '32'), (torch.float64, '64')):
+        uw, uh = p[:, :K].to(dt).clone(), p[:, K:].to(dt).clone()
+        if tails:
+            y, ld, bins = O.unconstrained_quadratic_spline(x.to(dt), uw, uh, inverse=inv, tail_bound=Tb, return_bins=True)
+        else:
+            y, ld, bins = O.quadratic_spline(x.to(dt), uw, uh, inverse=inv, return_bins=True)
+        assert torch.equal(bins, T(fx[direction + '_bins' + sfx]).long())
+        assert torch.equal(y, T(fx[direction + '_y' + sfx]), ) or rel_err(y, T(fx[direction + '_y' + sfx])) == 0
+        assert torch.equal(ld, T(fx[direction + '_ld' + sfx]))
+    with pytest.raises(ValueError):
+        O.quadratic_spline(torch.rand(4), torch.zeros(4, 2000), torch.zeros(4, 2001))
