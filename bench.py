@@ -85,6 +85,9 @@ def main():
     ap.add_argument('--dtype', default='f16x2', choices=['f32', 'bf16', 'bf16x3', 'f16x2'],
                     help='matrix arithmetic of the dominant layer (see the module docstring)')
     ap.add_argument('--cpu-sample', type=int, default=2048)
+    ap.add_argument('--stream-total', type=int, default=0,
+                    help='cfg-4: this many samples per GPU per step, generated on the device and pushed through in '
+                         'groups of --batch rows (nothing of size [total, D] is ever resident)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-bf16', action='store_true', help='skip the secondary measurements in the other modes')
     args = ap.parse_args()
@@ -113,7 +116,26 @@ def main():
     B = args.batch
     x = torch.randn(B, D, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
 
+    gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    xbuf = torch.empty_like(x) if args.stream_total else None
+
     def step():
+        if args.stream_total:
+            # cfg-4: the shard is produced group by group on the device; only per-group [sum, count] survive
+            acc = torch.zeros(2, dtype=torch.float64, device=dev)
+            done, logp = 0, None
+            with torch.no_grad():
+                while done < args.stream_total:
+                    n = min(B, args.stream_total - done)
+                    xb = xbuf[:n].normal_(generator=gen)
+                    logp = flow.log_prob(xb)
+                    acc[0] += logp.double().sum()
+                    acc[1] += n
+                    done += n
+            if dist is not None:
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            s_, n_ = acc.tolist()
+            return logp, (s_, n_)
         with torch.no_grad():
             logp = flow.log_prob(x)
         # the log-likelihood reduction of the sharded batch: [sum, count] in fp64, one all-reduce
@@ -144,7 +166,8 @@ def main():
 
     kern = timer.summary()
     if rank == 0:
-        total = world * B * args.steps
+        per_step = args.stream_total if args.stream_total else B
+        total = world * per_step * args.steps
         out = {
             'metric': 'log_prob samples/sec (fwd+logdet), RQ-spline MAF D=784',
             'value': total / elapsed, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
@@ -153,7 +176,8 @@ def main():
             'dtype': DTYPE_LABEL[args.dtype],
             'data': 'synthetic N(0,I) samples, default-init weights (seed 0)',
             'config': {'workload': 'cfg3: 5x RQ-spline MAF layer D=784 H=512 K=8 tails=linear T=3, log_prob',
-                       'batch_per_gpu': B, 'global_batch': world * B, 'parallelism': 'batch-sharded x%d' % world,
+                       'batch_per_gpu': per_step, 'global_batch': world * per_step, 'rows_per_pass': B,
+                       'streamed': bool(args.stream_total), 'parallelism': 'batch-sharded x%d' % world,
                        'chunk_rows': nf.transforms.CHUNK_ROWS},
             'mean_log_prob': ll_sum / ll_count,
         }
@@ -187,7 +211,7 @@ def main():
                                     'unit': 'GB/s', 'frac': byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                     'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': byts}
         out['kernel_ms'] = {'%s_%dx%d_rows%d' % (k[0], k[1], k[2], k[3]): round(v[1], 4) for k, v in kern.items()}
-        if not args.no_bf16:
+        if not args.no_bf16 and not args.stream_total:
             # secondary figures: the same step in the other matrix modes (this rank's shard)
             out['other_modes'] = {}
             for mode in ('f32', 'bf16x3', 'f16x2', 'bf16'):

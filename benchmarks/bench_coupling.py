@@ -39,7 +39,9 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--cpu-sample', type=int, default=131072)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16x3', 'f16x2', 'bf16'])
     args = ap.parse_args()
+    nf.set_matmul_dtype(args.dtype)
     flow = build(args.tail_bound)
     sd = {k: v.clone() for k, v in flow.state_dict().items()}
     flow = flow.cuda().eval()
@@ -54,7 +56,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     bytes_per_sample = L * 3460
     out = {'metric': 'log_prob samples/sec, 8x RQ-coupling D=64 (cfg-2)', 'value': args.batch / dt, 'unit': 'samples/s',
-           'ms_per_step': dt * 1e3, 'batch': args.batch, 'tail_bound': args.tail_bound, 'dtype': 'f32',
+           'ms_per_step': dt * 1e3, 'batch': args.batch, 'tail_bound': args.tail_bound, 'dtype': args.dtype,
            'roofline': {'bound': 'hbm', 'achieved': args.batch * bytes_per_sample / dt / 1e9, 'peak': 8000.0,
                         'unit': 'GB/s', 'frac': args.batch * bytes_per_sample / dt / 1e9 / 8000.0,
                         'algorithmic_bytes_per_sample': bytes_per_sample}}
