@@ -123,6 +123,15 @@ int nf_quadratic_spline_fwd(const float* x, int64_t x_row_stride, const int32_t*
                             int accumulate, int32_t* bin_idx, int64_t B, int D, int K, int tails, double tail_bound,
                             double min_bin_width, double min_bin_height, int inverse, void* stream);
 
+/* Monotone piecewise-cubic spline on [-bound, bound] (replaces splines/cubic.py:56-221 `cubic_spline`, whose
+ * default bound is 10, and with tails != 0 :14-54 `unconstrained_cubic_spline`): per element K unnormalised
+ * widths, K unnormalised heights, the unnormalised left and right boundary derivatives (P = 2K + 2).
+ * pre_div: the coupling layers' division of the width / height logits by sqrt(hidden_features). */
+int nf_cubic_spline_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index, const float* params,
+                        int64_t param_row_stride, double pre_div, float* y, int64_t y_row_stride, float* logabsdet,
+                        int accumulate, int32_t* bin_idx, int64_t B, int D, int K, int tails, double bound,
+                        double min_bin_width, double min_bin_height, int inverse, void* stream);
+
 /* ---- final MADE layer fused with the spline: `params` never reaches HBM ---------------------------
  *      (replaces made.py:358 `self.final_layer(outputs)` + transforms.py:819-860 `_elementwise` +
  *       rational_quadratic.py:13-149 in one launch; the forward AND the per-pass inverse of the

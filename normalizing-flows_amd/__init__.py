@@ -6,7 +6,8 @@ from .made import MADE, MaskedLinear, DenseLinear, MaskedResidualBlock, MaskedFe
 from .resnet import ResidualNet, ResidualBlock
 from .transforms import CompositeTransform, AutoregressiveTransform, MaskedAffineAutoregressiveTransform, \
     MaskedPiecewiseRationalQuadraticAutoregressiveTransform, MaskedPiecewiseLinearAutoregressiveTransform, \
-    MaskedPiecewiseQuadraticAutoregressiveTransform, CouplingTransform, AffineCouplingTransform, \
+    MaskedPiecewiseQuadraticAutoregressiveTransform, MaskedPiecewiseCubicAutoregressiveTransform, \
+    PiecewiseCubicCouplingTransform, CouplingTransform, AffineCouplingTransform, \
     PiecewiseRationalQuadraticCouplingTransform
 from . import parallel, metrics
 from .checkpoint import save_checkpoint, load_checkpoint

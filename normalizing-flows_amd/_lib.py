@@ -55,6 +55,10 @@ _SIGNATURES = {
                                            _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int,
                                            _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
                                            _c.c_void_p]),
+    'nf_cubic_spline_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_double,
+                                       _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int,
+                                       _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
+                                       _c.c_void_p]),
     'nf_affine_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
                                  _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_int,
                                  _c.c_int, _c.c_void_p]),
@@ -576,6 +580,21 @@ def quadratic_spline(x, params, num_bins, tails=None, tail_bound=1.0, inverse=Fa
                                            int(accumulate), _ptr(bins), B, D, int(num_bins),
                                            1 if tails == 'linear' else 0, float(tail_bound), float(min_bin_width),
                                            float(min_bin_height), int(inverse), _stream()), 'nf_quadratic_spline_fwd')
+    return out, logabsdet, bins
+
+
+def cubic_spline(x, params, num_bins, tails=None, bound=10.0, inverse=False, pre_div=1.0, feat_index=None, out=None,
+                 logabsdet=None, accumulate=False, min_bin_width=1e-3, min_bin_height=1e-3, want_bins=False,
+                 num_features=None):
+    """Monotone piecewise-cubic spline on [-bound, bound]: params [B, D*(2K+2)]."""
+    lib = load()
+    B, D, xp, xs, pp, ps, out, yp, ys, logabsdet, accumulate, bins = _family_call(
+        x, params, out, logabsdet, accumulate, want_bins, num_features)
+    with torch.cuda.device(x.device):
+        _check(lib.nf_cubic_spline_fwd(xp, xs, _ptr(feat_index), pp, ps, float(pre_div), yp, ys, logabsdet.data_ptr(),
+                                       int(accumulate), _ptr(bins), B, D, int(num_bins), 1 if tails == 'linear' else 0,
+                                       float(bound), float(min_bin_width), float(min_bin_height), int(inverse),
+                                       _stream()), 'nf_cubic_spline_fwd')
     return out, logabsdet, bins
 
 

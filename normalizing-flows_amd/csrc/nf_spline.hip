@@ -56,7 +56,7 @@ __device__ __forceinline__ float4 load_vec(const float* __restrict__ params, int
     return v;
 }
 
-// FAM: 0 rational-quadratic, 1 linear, 2 quadratic spline (nf_spline_families.h); the staging is the same
+// FAM: 0 rational-quadratic, 1 linear, 2 quadratic, 3 cubic spline (nf_spline_families.h); the staging is the same
 template <int KT, bool INV, int MAXV, int FAM = 0>
 __global__ __launch_bounds__(kThreads) void rqs_kernel(const RqsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(kThreads) void rqs_kernel(const RqsArgs a) {
             int bin;
             if (FAM == 1) lin_eval<INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
             else if (FAM == 2) quad_eval<INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
+            else if (FAM == 3) cubic_eval<INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
             else rqs_eval<KT, INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
             a.y[(row0 + r) * a.y_stride + col] = yv;
             if (a.bins) a.bins[(row0 + r) * (int64_t)D + d] = bin;
@@ -321,7 +322,7 @@ template <int FAM>
 int family_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index, const float* params,
                int64_t param_row_stride, float* y, int64_t y_row_stride, float* logabsdet, int accumulate,
                int32_t* bin_idx, int64_t B, int D, int K, int P, int tails, double tail_bound, double min_w,
-               double min_h, int inverse, void* stream) {
+               double min_h, int inverse, void* stream, double pre_div = 1.0, bool symmetric = false) {
     if (B == 0) return NF_OK;
     if (!x || !params || !y || !logabsdet) return NF_ERR_NULL;
     if (param_row_stride != (int64_t)D * P) return NF_ERR_LAYOUT;
@@ -331,8 +332,13 @@ int family_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index, 
     a.params = params; a.n_param_floats = B * (int64_t)D * P;
     a.y = y; a.y_stride = y_row_stride; a.lad = logabsdet; a.accumulate = accumulate; a.bins = bin_idx;
     a.B = B; a.D = D;
-    a.c = nf_make_rqs_const(K, tails, tail_bound, min_w, min_h, 1e-3, 1.0);
+    a.c = nf_make_rqs_const(K, tails, tail_bound, min_w, min_h, 1e-3, pre_div);
     a.c.P = P;
+    if (symmetric) {                       // the cubic spline lives on [-bound, bound] with or without tails
+        a.c.left = (float)-tail_bound;
+        a.c.right = (float)tail_bound;
+        a.c.span = (float)(2.0 * tail_bound);
+    }
     a.rows_per_block = pick_rows_per_block(D, B);
     a.vec_ok = ((uintptr_t)params & 15) == 0;
     const int stage_floats = (kThreads * P + 4 + 3) & ~3;
@@ -365,6 +371,18 @@ extern "C" int nf_quadratic_spline_fwd(const float* x, int64_t x_row_stride, con
     return family_fwd<2>(x, x_row_stride, feat_index, params, param_row_stride, y, y_row_stride, logabsdet, accumulate,
                          bin_idx, B, D, K, tails ? 2 * K - 1 : 2 * K + 1, tails, tail_bound, min_bin_width,
                          min_bin_height, inverse, stream);
+}
+
+extern "C" int nf_cubic_spline_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index, const float* params,
+                                   int64_t param_row_stride, double pre_div, float* y, int64_t y_row_stride,
+                                   float* logabsdet, int accumulate, int32_t* bin_idx, int64_t B, int D, int K,
+                                   int tails, double bound, double min_bin_width, double min_bin_height, int inverse,
+                                   void* stream) {
+    if (B < 0 || D <= 0 || K <= 0 || K > 32 || !(bound > 0.0) || !(pre_div > 0.0)) return NF_ERR_SHAPE;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+    return family_fwd<3>(x, x_row_stride, feat_index, params, param_row_stride, y, y_row_stride, logabsdet, accumulate,
+                         bin_idx, B, D, K, 2 * K + 2, tails, bound, min_bin_width, min_bin_height, inverse, stream,
+                         pre_div, true);
 }
 
 extern "C" int nf_rqs_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index,

@@ -150,3 +150,122 @@ __device__ __forceinline__ void quad_eval(const float* __restrict__ p, float x, 
     ld = INV ? (-l - lc) + lc : (l + lc) - lc;      // the reference's + log(top-bottom) - log(right-left), :131-135
     bin = b;
 }
+
+// Cubic spline (cubic.py:56-221; tails :14-54): p[0..K) unnormalised widths, p[K..2K) unnormalised heights,
+// p[2K], p[2K+1] unnormalised left / right boundary derivatives.  The interval is [a.left, a.right] in both
+// directions (the reference's default is [-10, 10]); a.pre_div divides the width / height logits (coupling).
+// eps and the near-quadratic threshold are the reference's defaults (1e-5, 1e-3).
+template <bool INV>
+__device__ __forceinline__ void cubic_eval(const float* __restrict__ p, float x, const RqsConst& a, float& y, float& ld,
+                                           int& bin) {
+    const int K = a.K;
+    if (a.tails && !(x >= a.left && x <= a.right)) {
+        y = x;
+        ld = 0.0f;
+        bin = -1;
+        return;
+    }
+    const float* uw = p;
+    const float* uh = p + K;
+    const bool scaled = a.pre_div != 1.0f;
+    auto raw = [&](const float* u, int k) { return scaled ? u[k] / a.pre_div : u[k]; };
+    const float t = (x - a.left) / a.span;
+    float mw = -INFINITY, mh = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        mw = fmaxf(mw, raw(uw, k));
+        mh = fmaxf(mh, raw(uh, k));
+    }
+    float sw = 0.0f, sh_ = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        sw += nf_exp(raw(uw, k) - mw);
+        sh_ += nf_exp(raw(uh, k) - mh);
+    }
+    auto width = [&](int k) { return a.min_w + a.scale_w * (nf_exp(raw(uw, k) - mw) / sw); };
+    auto height = [&](int k) { return a.min_h + a.scale_h * (nf_exp(raw(uh, k) - mh) / sh_); };
+    // bin search over the running sums
+    double accw = 0.0, acch = 0.0;
+    float cw0 = 0.0f, ch0 = 0.0f, lw = 0.0f, rw = 1.0f, d = 0.0f;
+    int b = 0;
+    for (int k = 0; k < K; ++k) {
+        accw += (double)width(k);
+        acch += (double)height(k);
+        float cw1 = (float)accw, ch1 = (float)acch;
+        if (k == K - 1) {                              // pinned to 1; the searched one is then raised by 1e-6
+            cw1 = INV ? 1.0f : 1.0f + 1e-6f;
+            ch1 = INV ? 1.0f + 1e-6f : 1.0f;
+        }
+        const bool ge = INV ? (t >= ch0) : (t >= cw0);
+        if (ge) { b = k; lw = cw0; rw = cw1; d = ch0; }
+        cw0 = cw1;
+        ch0 = ch1;
+    }
+    // knot derivatives at the two ends of bin b
+    const float wb = width(b), sb = height(b) / wb;
+    auto interior = [&](float w0, float s0, float w1, float s1) {      // knot between bins (w0, s0) and (w1, s1)
+        const float m1 = fminf(fabsf(s0), fabsf(s1));
+        const float m2 = 0.5f * (w1 * s0 + w0 * s1) / (w0 + w1);
+        const float sg0 = (s0 > 0.f) - (s0 < 0.f), sg1 = (s1 > 0.f) - (s1 < 0.f);
+        return fminf(m1, m2) * (sg0 + sg1);
+    };
+    float dl, dr;
+    if (b == 0) {
+        dl = (1.0f / (1.0f + nf_exp(-p[2 * K]))) * 3.0f * sb;
+    } else {
+        const float w0 = width(b - 1);
+        dl = interior(w0, height(b - 1) / w0, wb, sb);
+    }
+    if (b == K - 1) {
+        dr = (1.0f / (1.0f + nf_exp(-p[2 * K + 1]))) * 3.0f * sb;
+    } else {
+        const float w1 = width(b + 1);
+        dr = interior(wb, sb, w1, height(b + 1) / w1);
+    }
+    const float ca = (dl + dr - 2.0f * sb) / (wb * wb);
+    const float cb = (3.0f * sb - 2.0f * dl - dr) / wb;
+    const float cc = dl;
+    const float lc = (float)log((double)a.span);
+    if (!INV) {
+        const float s = t - lw;
+        const float o = ca * (s * s * s) + cb * (s * s) + cc * s + d;
+        y = o * a.span + a.left;
+        ld = nf_log(3.0f * ca * (s * s) + 2.0f * cb * s + cc);
+        ld = (ld + lc) - lc;
+    } else {
+        const float b_ = (cb / ca) / 3.0f;
+        const float c_ = (cc / ca) / 3.0f;
+        const float d_ = (d - t) / ca;
+        const float delta_1 = -(b_ * b_) + c_;
+        const float delta_2 = -c_ * b_ + d_;
+        const float delta_3 = b_ * d_ - c_ * c_;
+        const float disc = 4.0f * delta_1 * delta_3 - delta_2 * delta_2;
+        const float dep_1 = -2.0f * b_ * delta_1 + delta_2;
+        float o;
+        if (disc < 0.0f) {                                            // one real root (Cardano)
+            const float r = sqrtf(-disc);
+            const float u = (-dep_1 + r) / 2.0f, v = (-dep_1 - r) / 2.0f;
+            // (expf, not nf_exp: u or v can be exactly 0, and exp(-inf) must be 0 as in helper_functions.py:514-516)
+            const float cu = ((u > 0.f) - (u < 0.f)) * expf(logf(fabsf(u)) / 3.0f);
+            const float cv = ((v > 0.f) - (v < 0.f)) * expf(logf(fabsf(v)) / 3.0f);
+            o = (cu + cv) - b_ + lw;
+        } else {                                                      // three real roots: the one inside the bin
+            const float th = atan2f(sqrtf(disc), -dep_1) / 3.0f;
+            const float c1 = cosf(th), s1 = sinf(th);
+            const float scale = 2.0f * sqrtf(-delta_1), shift = -b_ + lw;
+            const float hs3 = 0.5f * 1.7320508075688772f;
+            const float r1 = c1 * scale + shift;
+            const float r2 = (-0.5f * c1 - hs3 * s1) * scale + shift;
+            const float r3 = (-0.5f * c1 + hs3 * s1) * scale + shift;
+            const float lo = lw - 1e-5f, hi = rw + 1e-5f;
+            o = (lo < r1 && r1 < hi) ? r1 : ((lo < r2 && r2 < hi) ? r2 : ((lo < r3 && r3 < hi) ? r3 : r1));
+        }
+        if (fabsf(ca) < 1e-3f) {                                      // almost quadratic: re-solve (:186-192)
+            const float qc = d - t;
+            o = (-cc + sqrtf(cc * cc - 4.0f * cb * qc)) / (2.0f * cb) + lw;
+        }
+        const float s = o - lw;
+        y = o * a.span + a.left;
+        ld = -nf_log(3.0f * ca * (s * s) + 2.0f * cb * s + cc);
+        ld = (ld - lc) + lc;
+    }
+    bin = b;
+}

@@ -343,6 +343,30 @@ class MaskedPiecewiseQuadraticAutoregressiveTransform(AutoregressiveTransform):
                               min_bin_height=self.min_bin_height)
 
 
+class MaskedPiecewiseCubicAutoregressiveTransform(AutoregressiveTransform):
+    """Monotone piecewise-cubic spline on [-10, 10] (the default interval of models/splines/cubic.py:56-67, which
+    is what reference transforms.py:707-769 calls) with MADE-produced widths, heights and boundary derivatives."""
+
+    def __init__(self, num_bins, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu, dropout_probability=0.,
+                 use_batch_norm=False):
+        self.num_bins = num_bins
+        self.features = features
+        made = made_module.MADE(
+            features=features, hidden_features=hidden_features, context_features=context_features,
+            num_blocks=num_blocks, output_multiplier=self._output_dim_multiplier(),
+            use_residual_blocks=use_residual_blocks, random_mask=random_mask, activation=activation,
+            dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        return self.num_bins * 2 + 2
+
+    def _elementwise(self, inputs, params, outputs, logabsdet, inverse):
+        _lib.cubic_spline(inputs, params, self.num_bins, tails=None, bound=10.0, inverse=inverse, out=outputs,
+                          logabsdet=logabsdet)
+
+
 # ------------------------------------------------------------------------------------ coupling
 class CouplingTransform(nn.Module):
     """Splits features by a binary mask; the identity half conditions the transform of the other
@@ -492,3 +516,35 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                  pre_div=pre_div, feat_index=self._feat_index(), out=outputs, logabsdet=logabsdet,
                  min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                  min_derivative=self.min_derivative, num_features=self.num_transform_features)
+
+
+class PiecewiseCubicCouplingTransform(CouplingTransform):
+    """Cubic-spline coupling layer (reference transforms.py:349-415): `tails=None` -> the spline's default interval
+    [-10, 10], 'linear' -> identity outside [-tail_bound, tail_bound]; width / height logits divided by
+    sqrt(hidden_features) when the conditioner exposes it."""
+
+    def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.,
+                 apply_unconditional_transform=False, img_shape=None, min_bin_width=DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=DEFAULT_MIN_BIN_HEIGHT):
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.tails = tails
+        self.tail_bound = tail_bound
+        if apply_unconditional_transform or img_shape:
+            raise NotImplementedError('unconditional / image transforms are outside this path')
+        super().__init__(mask, transform_net_create_fn, unconditional_transform=None)
+
+    def _transform_dim_multiplier(self):
+        return self.num_bins * 2 + 2
+
+    def _coupling_elementwise(self, inputs, transform_params, outputs, logabsdet, inverse):
+        pre_div = np.sqrt(self.transform_net.hidden_features) if hasattr(self.transform_net, 'hidden_features') else 1.0
+        if self.tails not in (None, 'linear'):
+            raise RuntimeError('{} tails are not implemented.'.format(self.tails))
+        _lib.cubic_spline(inputs, transform_params, self.num_bins, tails=self.tails,
+                          bound=10.0 if self.tails is None else self.tail_bound, inverse=inverse, pre_div=pre_div,
+                          feat_index=self._feat_index(), out=outputs, logabsdet=logabsdet,
+                          min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                          num_features=self.num_transform_features)
+

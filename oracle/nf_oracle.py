@@ -620,3 +620,127 @@ def unconstrained_quadratic_spline(inputs, uw, uh, inverse=False, tail_bound=1.,
         bins[inside] = res[2]
         return outputs, lad, bins
     return outputs, lad
+
+
+def cbrt(x):
+    """helper_functions.py:514-516."""
+    return torch.sign(x) * torch.exp(torch.log(torch.abs(x)) / 3.0)
+
+
+def cubic_spline(inputs, uw, uh, ul, ur, inverse=False, left=-10., right=10., bottom=-10., top=10.,
+                 min_bin_width=1e-3, min_bin_height=1e-3, eps=1e-5, quadratic_threshold=1e-3, return_bins=False):
+    """Monotone piecewise-cubic spline (Steffen-type knot derivatives), inverse by Cardano / the trigonometric
+    form with the root picked by bin membership, near-quadratic bins re-solved (models/splines/cubic.py:56-221)."""
+    nb = uw.shape[-1]
+    if min_bin_width * nb > 1.0:
+        raise ValueError('Minimal bin width too large for the number of bins')
+    if min_bin_height * nb > 1.0:
+        raise ValueError('Minimal bin height too large for the number of bins')
+    inputs = (inputs - bottom) / (top - bottom) if inverse else (inputs - left) / (right - left)
+    widths = F.softmax(uw, dim=-1)
+    widths = min_bin_width + (1 - min_bin_width * nb) * widths
+    cumw = torch.cumsum(widths, dim=-1)
+    cumw[..., -1] = 1
+    cumw = F.pad(cumw, pad=(1, 0), mode='constant', value=0.0)
+    heights = F.softmax(uh, dim=-1)
+    heights = min_bin_height + (1 - min_bin_height * nb) * heights
+    cumh = torch.cumsum(heights, dim=-1)
+    cumh[..., -1] = 1
+    cumh = F.pad(cumh, pad=(1, 0), mode='constant', value=0.0)
+    slopes = heights / widths
+    m1 = torch.min(torch.abs(slopes[..., :-1]), torch.abs(slopes[..., 1:]))
+    m2 = (0.5 * (widths[..., 1:] * slopes[..., :-1] + widths[..., :-1] * slopes[..., 1:])
+          / (widths[..., :-1] + widths[..., 1:]))
+    ms = torch.min(m1, m2)
+    d_left = torch.sigmoid(ul) * 3 * slopes[..., 0][..., None]
+    d_right = torch.sigmoid(ur) * 3 * slopes[..., -1][..., None]
+    deriv = ms * (torch.sign(slopes[..., :-1]) + torch.sign(slopes[..., 1:]))
+    deriv = torch.cat([d_left, deriv, d_right], dim=-1)
+    a = (deriv[..., :-1] + deriv[..., 1:] - 2 * slopes) / widths.pow(2)
+    b = (3 * slopes - 2 * deriv[..., :-1] - deriv[..., 1:]) / widths
+    c = deriv[..., :-1]
+    d = cumh[..., :-1]
+    idx = (searchsorted(cumh, inputs) if inverse else searchsorted(cumw, inputs))[..., None]
+    ia = a.gather(-1, idx)[..., 0]
+    ib = b.gather(-1, idx)[..., 0]
+    ic = c.gather(-1, idx)[..., 0]
+    id_ = d.gather(-1, idx)[..., 0]
+    lw = cumw.gather(-1, idx)[..., 0]
+    rw = cumw.gather(-1, idx + 1)[..., 0]
+    if inverse:
+        b_ = (ib / ia) / 3.
+        c_ = (ic / ia) / 3.
+        d_ = (id_ - inputs) / ia
+        delta_1 = -b_.pow(2) + c_
+        delta_2 = -c_ * b_ + d_
+        delta_3 = b_ * d_ - c_.pow(2)
+        disc = 4. * delta_1 * delta_3 - delta_2.pow(2)
+        dep_1 = -2. * b_ * delta_1 + delta_2
+        dep_2 = delta_1
+        three = disc >= 0
+        one = disc < 0
+        outputs = torch.zeros_like(inputs)
+        p = cbrt((-dep_1[one] + torch.sqrt(-disc[one])) / 2.)
+        q = cbrt((-dep_1[one] - torch.sqrt(-disc[one])) / 2.)
+        outputs[one] = (p + q) - b_[one] + lw[one]
+        theta = torch.atan2(torch.sqrt(disc[three]), -dep_1[three])
+        theta /= 3.
+        cr1 = torch.cos(theta)
+        cr2 = torch.sin(theta)
+        r1 = cr1
+        r2 = -0.5 * cr1 - 0.5 * math.sqrt(3) * cr2
+        r3 = -0.5 * cr1 + 0.5 * math.sqrt(3) * cr2
+        scale = 2 * torch.sqrt(-dep_2[three])
+        shift = -b_[three] + lw[three]
+        r1 = r1 * scale + shift
+        r2 = r2 * scale + shift
+        r3 = r3 * scale + shift
+        k1 = ((lw[three] - eps) < r1).float()
+        k1 *= (r1 < (rw[three] + eps)).float()
+        k2 = ((lw[three] - eps) < r2).float()
+        k2 *= (r2 < (rw[three] + eps)).float()
+        k3 = ((lw[three] - eps) < r3).float()
+        k3 *= (r3 < (rw[three] + eps)).float()
+        roots = torch.stack([r1, r2, r3], dim=-1)
+        masks = torch.stack([k1, k2, k3], dim=-1)
+        pick = torch.argsort(masks, dim=-1, descending=True)[..., 0][..., None]
+        outputs[three] = torch.gather(roots, dim=-1, index=pick).view(-1)
+        quad = ia.abs() < quadratic_threshold
+        qa = ib[quad]
+        qb = ic[quad]
+        qc = id_[quad] - inputs[quad]
+        alpha = (-qb + torch.sqrt(qb.pow(2) - 4 * qa * qc)) / (2 * qa)
+        outputs[quad] = alpha + lw[quad]
+        sh = outputs - lw
+        lad = -torch.log(3 * ia * sh.pow(2) + 2 * ib * sh + ic)
+    else:
+        sh = inputs - lw
+        outputs = ia * sh.pow(3) + ib * sh.pow(2) + ic * sh + id_
+        lad = torch.log(3 * ia * sh.pow(2) + 2 * ib * sh + ic)
+    if inverse:
+        outputs = outputs * (right - left) + left
+        lad = lad - math.log(top - bottom) + math.log(right - left)
+    else:
+        outputs = outputs * (top - bottom) + bottom
+        lad = lad + math.log(top - bottom) - math.log(right - left)
+    if return_bins:
+        return outputs, lad, idx[..., 0]
+    return outputs, lad
+
+
+def unconstrained_cubic_spline(inputs, uw, uh, ul, ur, inverse=False, tail_bound=1., min_bin_width=1e-3,
+                               min_bin_height=1e-3, return_bins=False):
+    """Identity outside [-T, T] (models/splines/cubic.py:14-54)."""
+    inside = (inputs >= -tail_bound) & (inputs <= tail_bound)
+    outputs = torch.zeros_like(inputs)
+    lad = torch.zeros_like(inputs)
+    outputs[~inside] = inputs[~inside]
+    res = cubic_spline(inputs[inside], uw[inside, :], uh[inside, :], ul[inside, :], ur[inside, :], inverse=inverse,
+                       left=-tail_bound, right=tail_bound, bottom=-tail_bound, top=tail_bound,
+                       min_bin_width=min_bin_width, min_bin_height=min_bin_height, return_bins=return_bins)
+    outputs[inside], lad[inside] = res[0], res[1]
+    if return_bins:
+        bins = torch.full(inputs.shape, -1, dtype=torch.int64)
+        bins[inside] = res[2]
+        return outputs, lad, bins
+    return outputs, lad

@@ -21,6 +21,7 @@ sys.path.insert(0, "/root/reference")
 import helper_functions  # noqa: E402  (must precede models.*)
 from models.splines import linear as ref_lin  # noqa: E402
 from models.splines import quadratic as ref_quad  # noqa: E402
+from models.splines import cubic as ref_cub  # noqa: E402
 
 _last = {}
 _orig = helper_functions.searchsorted
@@ -104,6 +105,42 @@ def gen_quadratic():
         save('quadspline_' + tag, **arrays)
 
 
+def gen_cubic():
+    for (K, T, tails, tag) in [(8, 3.0, True, 'K8_T3'), (6, 10.0, False, 'K6_pm10'), (16, 5.0, True, 'K16_T5')]:
+        g = torch.Generator().manual_seed(500 + K)
+        N = 4096
+        params = torch.randn(N, 2 * K + 2, generator=g)
+        params[N // 2:] *= 2.0
+        uw, uh, ul, ur = params[:, :K], params[:, K:2 * K], params[:, 2 * K:2 * K + 1], params[:, 2 * K + 1:]
+        arrays = {'params': params, 'num_bins': K, 'tail_bound': T, 'tails': int(tails)}
+        for inverse, key in [(False, 'fwd'), (True, 'inv')]:
+            x = torch.randn(N, generator=g) * (0.6 * T)
+            edge = torch.tensor([-T, T, 0.0] + ([2 * T, -2 * T] if tails else []), dtype=torch.float32)
+            if not tails:
+                x = x.clamp(-T, T)
+            x[:len(edge)] = edge
+            outs = {}
+            for dt, sfx in ((torch.float32, '32'), (torch.float64, '64')):
+                _last.clear()
+                args = [v.to(dt).clone() for v in (uw, uh, ul, ur)]
+                if tails:
+                    y, ld = ref_cub.unconstrained_cubic_spline(x.to(dt), *args, inverse=inverse, tail_bound=T)
+                    inside = (x >= -T) & (x <= T)
+                    bins = torch.full((N,), -1, dtype=torch.int64)
+                    bins[inside] = _last['idx']
+                else:
+                    y, ld = ref_cub.cubic_spline(x.to(dt), *args, inverse=inverse)
+                    bins = _last['idx']
+                outs['y' + sfx], outs['ld' + sfx], outs['bins' + sfx] = y, ld, bins.to(torch.int16)
+            arrays.update({key + '_x': x, key + '_n_edge': len(edge), **{key + '_' + k: v for k, v in outs.items()}})
+        save('cubspline_' + tag, **arrays)
+
+
 if __name__ == '__main__':
-    gen_linear()
-    gen_quadratic()
+    which = sys.argv[1:] or ['linear', 'quadratic', 'cubic']
+    if 'linear' in which:
+        gen_linear()
+    if 'quadratic' in which:
+        gen_quadratic()
+    if 'cubic' in which:
+        gen_cubic()

@@ -784,3 +784,86 @@ def test_spline_family_autoregressive_transforms(nf, family):
     assert_close(ld, ld64, ld32)
     assert (xi.cpu() - x).abs().max().item() < 1e-4 and (ldi + ld).abs().max().item() < 1e-3
 
+
+def _assert_close_noisy(got, ref64, ref32):
+    """For the cubic spline, whose fp32 evaluation is noisy in the reference itself (Cardano / trigonometric roots,
+    a -> 0 bins: the reference's fp32 run is up to 3e-2 from its fp64 run on these fixtures): quantile bounds tied
+    to the reference's own fp32-vs-fp64 distances instead of a flat 1e-5."""
+    got = torch.as_tensor(got).double().cpu().reshape(-1)
+    ref64 = torch.as_tensor(ref64).double().reshape(-1)
+    r32 = torch.as_tensor(ref32).double().reshape(-1)
+    ok = ~(torch.isnan(ref64) | torch.isnan(r32))
+    e = ((got - ref64).abs() / ref64.abs().clamp_min(1.0))[ok]
+    f = ((r32 - ref64).abs() / ref64.abs().clamp_min(1.0))[ok]
+    assert not torch.isnan(e).any()
+    for qq, base in ((0.5, 1e-6), (0.99, 1e-5), (0.999, 1e-4)):
+        assert torch.quantile(e, qq).item() <= max(base, 4 * torch.quantile(f, qq).item()), qq
+    assert e.max().item() <= max(1e-3, 16 * f.max().item())
+
+
+@pytest.mark.parametrize('tag', ['K8_T3', 'K6_pm10', 'K16_T5'])
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_cubic_spline_golden(nf, tag, direction):
+    fx = load_golden('cubspline_' + tag)
+    K, Tb, tails = int(fx['num_bins']), float(fx['tail_bound']), 'linear' if int(fx['tails']) else None
+    x = dev(fx[direction + '_x']).reshape(-1, 1)
+    y, ld, bins = nf._lib.cubic_spline(x, dev(fx['params']), K, tails=tails, bound=Tb, inverse=direction == 'inv',
+                                       want_bins=True)
+    _assert_close_noisy(y.reshape(-1), fx[direction + '_y64'], fx[direction + '_y32'])
+    _assert_close_noisy(ld, fx[direction + '_ld64'], fx[direction + '_ld32'])
+    b64 = T(fx[direction + '_bins64']).long()
+    assert (bins.cpu().reshape(-1).long() == b64).float().mean().item() > 0.999
+
+
+def test_cubic_transforms_against_the_oracle(nf):
+    """MaskedPiecewiseCubicAutoregressiveTransform and PiecewiseCubicCouplingTransform (linear tails, logits /
+    sqrt(hidden)) end to end against the oracle's conditioner + cubic spline, plus the round trip."""
+    torch.manual_seed(14)
+    D, H, K, B = 8, 32, 5, 190
+    t = nf.MaskedPiecewiseCubicAutoregressiveTransform(K, D, H)
+    sd = {k: v.detach().clone() for k, v in t.state_dict().items()}
+    t = t.cuda().eval()
+    x = torch.randn(B, D) * 2.0
+    with torch.no_grad():
+        y, ld = t(x.cuda())
+        xi, ldi = t.inverse(y)
+    mult = 2 * K + 2
+
+    def ref(dt):
+        sdd = {k: (w.to(dt) if w.is_floating_point() else w) for k, w in sd.items()}
+        p = O.made_forward(sdd, x.to(dt), 'autoregressive_net.').view(B, D, mult)
+        yy, ll = O.cubic_spline(x.to(dt), p[..., :K], p[..., K:2 * K], p[..., 2 * K:2 * K + 1], p[..., 2 * K + 1:])
+        return yy, O.sum_except_batch(ll)
+    (y64, ld64), (y32, ld32) = ref(torch.float64), ref(torch.float32)
+    _assert_close_noisy(y, y64, y32)
+    _assert_close_noisy(ld, ld64, ld32)
+    assert torch.quantile((xi.cpu() - x).abs().reshape(-1), 0.99).item() < 1e-3
+
+    mask = torch.zeros(D)
+    mask[::2] = 1
+    c = nf.PiecewiseCubicCouplingTransform(mask, lambda i, o: nf.ResidualNet(i, o, hidden_features=32, num_blocks=1),
+                                           num_bins=K, tails='linear', tail_bound=3.0)
+    with torch.no_grad():
+        for p_ in c.parameters():
+            p_.mul_(2.0)
+    csd = {k: v.detach().clone() for k, v in c.state_dict().items()}
+    c = c.cuda().eval()
+    with torch.no_grad():
+        yc, ldc = c(x.cuda())
+        xc, _ = c.inverse(yc)
+
+    def cref(dt):
+        sdd = {k: (w.to(dt) if w.is_floating_point() else w) for k, w in csd.items()}
+
+        def elementwise(xt, params):
+            tp = params.reshape(xt.shape[0], xt.shape[1], mult)
+            uw, uh = tp[..., :K] / np.sqrt(32), tp[..., K:2 * K] / np.sqrt(32)
+            yy, ll = O.unconstrained_cubic_spline(xt, uw, uh, tp[..., 2 * K:2 * K + 1], tp[..., 2 * K + 1:], tail_bound=3.0)
+            return yy, O.sum_except_batch(ll)
+        return O._coupling(sdd, x.to(dt), elementwise)
+    (cy64, cl64), (cy32, cl32) = cref(torch.float64), cref(torch.float32)
+    _assert_close_noisy(yc, cy64, cy32)
+    _assert_close_noisy(ldc, cl64, cl32)
+    assert torch.equal(yc[:, c.identity_features], x.cuda()[:, c.identity_features])
+    assert torch.quantile((xc.cpu() - x).abs().reshape(-1), 0.99).item() < 1e-3
+

@@ -237,3 +237,22 @@ def test_quadratic_spline_family(tag, direction):
         assert torch.equal(ld, T(fx[direction + '_ld' + sfx]))
     with pytest.raises(ValueError):
         O.quadratic_spline(torch.rand(4), torch.zeros(4, 2000), torch.zeros(4, 2001))
+
+
+@pytest.mark.parametrize('tag', ['K8_T3', 'K6_pm10', 'K16_T5'])
+@pytest.mark.parametrize('direction', ['fwd', 'inv'])
+def test_cubic_spline_family(tag, direction):
+    fx = load_golden('cubspline_' + tag)
+    K, Tb, tails = int(fx['num_bins']), float(fx['tail_bound']), bool(int(fx['tails']))
+    p, x, inv = T(fx['params']), T(fx[direction + '_x']), direction == 'inv'
+    for dt, sfx in ((torch.float32, '32'), (torch.float64, '64')):
+        args = [v.to(dt).clone() for v in (p[:, :K], p[:, K:2 * K], p[:, 2 * K:2 * K + 1], p[:, 2 * K + 1:])]
+        if tails:
+            y, ld, bins = O.unconstrained_cubic_spline(x.to(dt), *args, inverse=inv, tail_bound=Tb, return_bins=True)
+        else:
+            y, ld, bins = O.cubic_spline(x.to(dt), *args, inverse=inv, return_bins=True)
+        assert torch.equal(bins, T(fx[direction + '_bins' + sfx]).long())
+        ry, rl = T(fx[direction + '_y' + sfx]), T(fx[direction + '_ld' + sfx])
+        assert torch.equal(torch.isnan(y), torch.isnan(ry)) and torch.equal(torch.isnan(ld), torch.isnan(rl))
+        assert torch.equal(torch.nan_to_num(y), torch.nan_to_num(ry))     # same op sequence => same bits
+        assert torch.equal(torch.nan_to_num(ld), torch.nan_to_num(rl))
