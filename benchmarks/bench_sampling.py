@@ -23,8 +23,12 @@ def main():
     ap.add_argument('--layers', type=int, default=5)
     ap.add_argument('--dtype', default='f32')
     ap.add_argument('--reps', type=int, default=2)
+    ap.add_argument('--windowed', action='store_true', help='the windowed incremental inverse instead of the row-resident kernel')
     args = ap.parse_args()
     nf.set_matmul_dtype(args.dtype)
+    if args.windowed:
+        from normalizing_flows_amd import transforms as tr
+        tr.ROW_RESIDENT_INVERSE = False
     torch.manual_seed(0)
     D, H, K = 784, 512, 8
     layers = [nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, num_bins=K, tails='linear', tail_bound=3.)
@@ -42,7 +46,7 @@ def main():
         z2, ld2 = flow.reverse(x)
     print(json.dumps({'metric': 'inverse sampling samples/sec, RQ-spline MAF D=784', 'value': args.batch / dt,
                       'unit': 'samples/s', 'seconds': dt, 'batch': args.batch, 'layers': args.layers,
-                      'dtype': args.dtype, 'passes_per_layer': len(layers[0]._feature_groups()),
+                      'dtype': args.dtype, 'path': 'windowed' if args.windowed else 'row-resident', 'passes_per_layer': len(layers[0]._feature_groups()),
                       'roundtrip_max_abs_err': (z2 - z).abs().max().item(),
                       'logdet_cancel_max_abs': (ld + ld2).abs().max().item()}))
 

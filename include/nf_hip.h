@@ -234,6 +234,32 @@ int nf_resnet_hidden_fwd(const float* x, int64_t x_row_stride, const int32_t* in
                          const float* blob, int hidden, int num_blocks, float* h, int64_t h_row_stride,
                          int64_t B, void* stream);
 
+/* ---- autoregressive inverse, row-resident (replaces the D conditioner passes of transforms.py:493-500
+ *      for MaskedPiecewiseRationalQuadraticAutoregressiveTransform, made.py:352-359 + rational_quadratic.py) ----
+ * Requires hidden units in degree order (unit j has MADE degree j+1 in every hidden layer: the reference's
+ * non-random masks with hidden <= features - 1, made.py:142-146), ReLU, no BatchNorm / context, and
+ * P = 3K-1 (linear tails) or 3K+1 <= 32 parameters per feature.  One workgroup carries 32 samples through
+ * features 0..hidden; total work about one forward pass (see nf_inverse.hip). */
+int nf_made_rqs_inverse_rows_supported(int features, int hidden, int n_steps, int K, int tails);
+/* Length in floats of the parameter blob, HS = hidden rounded up to 64, H = hidden:
+ *   per hidden step s (initial layer, then each masked linear of the blocks, n_steps in all):
+ *       WT[H][HS]: WT[j][k] = weight[k][j] * mask[k][j] (input j < H -> unit k), bias[HS]
+ *   bf[H+1][32]: final-layer bias of feature f, parameters 0..P-1, zero padded
+ *   off[H+2 rounded up to 4] (int32 bit patterns): off[f] = sum over g < f of ceil(g / 8)
+ *   wf[off[H+1]][64][4]: for feature f, K super-step S < ceil(f/8), lane (kh = lane>>5, col = lane&31):
+ *       weight[f*P + col][8S + 4kh + 0..3] * mask (zero for col >= P) */
+size_t nf_made_inverse_blob_floats(int hidden, int n_steps);
+/* x[b, 0..hidden] = inverse of z[b, 0..hidden] feature by feature; hidden_out[b, :] = final hidden state;
+ * workspace = the [tiles][B] logdet partials of nf_made_rqs_fwd_tiles (tiles wholly below feature hidden+1
+ * are written).  The caller finishes features hidden+1.. with nf_made_rqs_fwd_tiles(tile_begin =
+ * (hidden+1) / features_per_tile, reduce = 1).  step_flags[s]: 1 = ReLU on the step's input, 2 = add the
+ * output of step s-2 (residual block), 4 = ReLU on the step's output (feed-forward block). */
+int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags, const float* z,
+                             int64_t z_row_stride, float* x, int64_t x_row_stride, float* hidden_out,
+                             int64_t h_row_stride, float* workspace, size_t workspace_bytes, int64_t B, int features,
+                             int K, int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                             double min_derivative, void* stream);
+
 /* ---- affine transform (replaces transforms.py:328-347 coupling, :540-566 autoregressive) -------- */
 
 /* scale = sigmoid(u + 2) + 1e-3; forward y = scale*x + shift, inverse y = (x - shift)/scale;

@@ -94,6 +94,12 @@ _SIGNATURES = {
     'nf_resnet_blob_floats': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_resnet_hidden_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p,
                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
+    'nf_made_rqs_inverse_rows_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'nf_made_inverse_blob_floats': (_c.c_size_t, [_c.c_int, _c.c_int]),
+    'nf_made_rqs_inverse_rows': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                            _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_size_t,
+                                            _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double,
+                                            _c.c_double, _c.c_double, _c.c_void_p]),
     'nf_made_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -450,6 +456,85 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
         _check(code, 'nf_made_rqs_fwd')
     out._nf_max = y_max                 # (None outside the split-operand whole-layer launches)
     return out, logabsdet, bins
+
+
+class PackedInverse:
+    """Parameter blob of nf_made_rqs_inverse_rows (layout: include/nf_hip.h) for a MADE whose hidden units are in
+    degree order.  `steps` = [(weight, mask, bias, flags)] of the hidden stack, then the final layer."""
+    __slots__ = ('hidden', 'features', 'P', 'K', 'tails', 'n_steps', 'flags', 'blob')
+
+    def __init__(self, steps, final_weight, final_mask, final_bias, features, num_bins, tails):
+        lib = load()
+        H = int(final_weight.shape[1])
+        t = 1 if tails == 'linear' else 0
+        P = 3 * num_bins - 1 if t else 3 * num_bins + 1
+        HS = (H + 63) // 64 * 64
+        dev = final_weight.device
+        parts, flags = [], []
+        for w, m, b, fl in steps:
+            w = _dev(w.detach(), 'weight')
+            wm = w if m is None else w * m
+            wt = torch.zeros((H + 1, HS), dtype=torch.float32, device=dev)
+            wt[:H, :H] = wm[:, :H].t()
+            if b is not None:
+                wt[H, :H] = b.detach()
+            parts.append(wt.reshape(-1))
+            flags.append(int(fl))
+        wf = _dev(final_weight.detach(), 'weight')
+        if final_mask is not None:
+            wf = wf * final_mask
+        wf = wf.view(features, P, H)[:H + 1]
+        bf = torch.zeros((H + 1, 32), dtype=torch.float32, device=dev)
+        if final_bias is not None:
+            bf[:, :P] = final_bias.detach().view(features, P)[:H + 1]
+        parts.append(bf.reshape(-1))
+        nss = (torch.arange(H + 2, device=dev) + 7) // 8                  # super-steps of feature f
+        off = torch.zeros((H + 2 + 3) // 4 * 4, dtype=torch.int32, device=dev)
+        off[1:H + 2] = torch.cumsum(nss[:H + 1], 0).to(torch.int32)
+        parts.append(off.view(torch.float32))
+        ns_max = (H + 7) // 8
+        dense = torch.zeros((H + 1, 32, ns_max * 8), dtype=torch.float32, device=dev)
+        dense[:, :P, :H] = wf
+        dense = dense.view(H + 1, 32, ns_max, 2, 4).permute(0, 2, 3, 1, 4)         # [f][S][kh][col][4]
+        live = torch.arange(ns_max, device=dev)[None, :] < nss[:H + 1, None]
+        parts.append(dense[live].reshape(-1))
+        self.blob = torch.cat(parts).contiguous()
+        self.hidden, self.features, self.P, self.K, self.tails = H, int(features), P, int(num_bins), t
+        self.n_steps, self.flags = len(steps), (ctypes.c_int * len(flags))(*flags)
+        if self.blob.numel() != lib.nf_made_inverse_blob_floats(H, self.n_steps):
+            raise RuntimeError('inverse blob has %d floats, the library expects %d'
+                               % (self.blob.numel(), lib.nf_made_inverse_blob_floats(H, self.n_steps)))
+
+
+def made_rqs_inverse_rows_supported(features, hidden, n_steps, num_bins, tails):
+    return (tails in (None, 'linear')
+            and load().nf_made_rqs_inverse_rows_supported(int(features), int(hidden), int(n_steps), int(num_bins),
+                                                          1 if tails == 'linear' else 0) == 1)
+
+
+def made_rqs_inverse_rows(pi, z, out, hidden, workspace, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,
+                          min_derivative=1e-3):
+    """Features 0..H of the autoregressive inverse for every row of z (nf_made_rqs_inverse_rows); leaves the final
+    hidden state in `hidden` and the logdet partials of the finished fused tiles in `workspace`."""
+    lib = load()
+    _dev(z, 'inputs')
+    _dev(out, 'outputs')
+    _dev(hidden, 'hidden')
+    B = z.shape[0]
+    zp, zs = _rows(z, 'inputs')
+    xp, xs = _rows(out, 'outputs')
+    hp, hs = _rows(hidden, 'hidden')
+    if z.shape[1] != pi.features or out.shape != z.shape or hidden.shape != (B, pi.hidden):
+        raise ValueError('Expected inputs / outputs [B,%d] and hidden [B,%d]' % (pi.features, pi.hidden))
+
+    def launch():
+        return lib.nf_made_rqs_inverse_rows(pi.blob.data_ptr(), pi.hidden, pi.n_steps, pi.flags, zp, zs, xp, xs, hp, hs,
+                                            workspace.data_ptr(), workspace.numel() * 4, B, pi.features, pi.K,
+                                            pi.tails, float(tail_bound), float(min_bin_width), float(min_bin_height),
+                                            float(min_derivative), _stream())
+    with torch.cuda.device(z.device):
+        code = launch() if _timer is None else _timer.record(('made_rqs_inverse_rows', pi.hidden, pi.features, B), launch)
+        _check(code, 'nf_made_rqs_inverse_rows')
 
 
 def resnet_hidden_supported(n_in, hidden):

@@ -102,9 +102,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // STRAIGHT: no early exit for tail elements (they are evaluated at the interval centre and replaced by
 // the identity at the end), so that several evaluations inlined back to back form one basic block the
 // scheduler can interleave.
-template <int KT, bool INV, int STRIDE = 1, bool BASE2 = false, bool STRAIGHT = false>
-__device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, const RqsConst& a,
-                                         float& y, float& ld, int& bin) {
+// PT: pointer type of the parameters (an explicit LDS address-space pointer keeps a runtime-K caller off flat loads).
+template <int KT, bool INV, int STRIDE = 1, bool BASE2 = false, bool STRAIGHT = false, class PT = const float*>
+__device__ __forceinline__ void rqs_eval(PT p, float x, const RqsConst& a, float& y, float& ld, int& bin) {
     const int K = KT > 0 ? KT : a.K;
     const bool outside = a.tails && !(x >= a.left && x <= a.right);   // linear tails: identity, logdet 0 (NaN too)
     const float x_in = x;
@@ -116,13 +116,13 @@ __device__ __forceinline__ void rqs_eval(const float* __restrict__ p, float x, c
         bin = -1;
         return;
     }
-    const float* uw = p;
-    const float* uh = p + K * STRIDE;
-    const float* ud = p + 2 * K * STRIDE;
+    const PT uw = p;
+    const PT uh = p + K * STRIDE;
+    const PT ud = p + 2 * K * STRIDE;
     const bool scaled = a.pre_div != 1.0f;
 
     // softmax denominators: max, then sum of exp(u - max) left to right
-    auto raw = [&](const float* u, int k) {
+    auto raw = [&](PT u, int k) {
         float v = u[k * STRIDE];
         return scaled ? nf_div(v, a.pre_div) : v;
     };

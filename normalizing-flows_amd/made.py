@@ -344,5 +344,32 @@ class MADE(nn.Module):
                         relu_in=relu_in, relu_out=relu_out, out=bufs[dst], tiles=tiles)
         return bufs[last]
 
+    def inverse_rows_pack(self, num_bins, tails):
+        """Parameter blob for the row-resident inverse kernel (nf_made_rqs_inverse_rows), or None when this
+        network is outside its scope: hidden units must be in degree order in every layer (the non-random masks
+        with hidden_features <= features - 1), no BatchNorm, the step structure of hidden_program()."""
+        steps, _ = self.hidden_program()
+        layers = [st[0] for st in steps] + [self.final_layer]
+        key = tuple((l.weight._version, l.weight.data_ptr(), None if l.bias is None else l.bias._version,
+                     l.mask._version) for l in layers) + (self.final_layer.weight.device, num_bins, tails)
+        cached = getattr(self, '_inverse_rows_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        D, H = self.initial_layer.in_features, self.final_layer.in_features
+        pack = None
+        ok = _lib.made_rqs_inverse_rows_supported(D, H, len(steps), num_bins, tails)
+        flags = []
+        want = torch.arange(1, H + 1)
+        for i, (layer, src, dst, res, relu_in, relu_out, bn) in enumerate(steps):
+            ok = ok and bn is None and torch.equal(layer.degrees.cpu(), want)
+            ok = ok and (i == 0 or src == steps[i - 1][2]) and (res is None or (i >= 2 and res == steps[i - 2][2]))
+            flags.append((1 if relu_in else 0) | (2 if res is not None else 0) | (4 if relu_out else 0))
+        if ok:
+            pack = _lib.PackedInverse([(st[0].weight, st[0].mask, st[0].bias, fl) for st, fl in zip(steps, flags)],
+                                      self.final_layer.weight, self.final_layer.mask, self.final_layer.bias, D,
+                                      num_bins, tails)
+        object.__setattr__(self, '_inverse_rows_cache', (key, pack))
+        return pack
+
     def forward(self, inputs, context=None):
         return self.final_layer.fused(self.forward_hidden(inputs, context))

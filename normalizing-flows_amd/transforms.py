@@ -28,6 +28,10 @@ DEFAULT_MIN_DERIVATIVE = 1e-3
 CHUNK_ROWS = 131072
 
 
+# False: always take the windowed incremental inverse (A/B measurements, tests of that path)
+ROW_RESIDENT_INVERSE = True
+
+
 def _check_2d(inputs, features):
     if inputs.dim() != 2:
         raise ValueError('Inputs must be a 2D tensor.')   # image (4D) inputs are outside this path
@@ -258,6 +262,24 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         fpt = 256 // self._output_dim_multiplier()        # whole features per fused column tile
         outputs = torch.zeros_like(inputs)
         logabsdet = torch.zeros(B, dtype=inputs.dtype, device=inputs.device)
+        pi = net.inverse_rows_pack(self.num_bins, self.tails) if ROW_RESIDENT_INVERSE else None
+        if pi is not None:
+            # hidden units in degree order: 32 samples per workgroup run features 0..H start to end in one launch
+            # (nf_inverse.hip, about one forward pass of work); the features past H+1 depend on no further hidden
+            # unit and take one windowed launch of the fused layer kernel on the final hidden state
+            t0 = (H + 1) // fpt
+            for s in range(0, B, CHUNK_ROWS):
+                e = min(B, s + CHUNK_ROWS)
+                z, out = inputs[s:e], outputs[s:e]
+                hidden = torch.empty((e - s, H), dtype=inputs.dtype, device=inputs.device)
+                ws = _lib.fused_workspace(pf, e - s, inputs.device, planes=False)
+                _lib.made_rqs_inverse_rows(pi, z, out, hidden, ws, self.tail_bound, self.min_bin_width,
+                                           self.min_bin_height, self.min_derivative)
+                _lib.made_rqs(hidden, pf, z, self.tail_bound, inverse=True, out=out, logabsdet=logabsdet[s:e],
+                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                              min_derivative=self.min_derivative, tiles=(t0, pf.tiles - t0), feat_limit=D,
+                              reduce=True, workspace=ws)
+            return outputs, logabsdet
         groups = self._feature_groups()
         names = {n for st in net.hidden_program()[0] for n in (st[1], st[2])} - {'x'}
         for s in range(0, B, CHUNK_ROWS):

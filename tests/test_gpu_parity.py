@@ -301,6 +301,7 @@ def test_rq_ar_incremental_inverse_equals_d_pass_loop(nf, tol=1e-5):
     """The incremental inverse (hidden tiles of one degree + one fused tile per pass) against the
     reference's algorithm run literally on the same kernels: D full passes from zeros."""
     from normalizing_flows_amd.transforms import AutoregressiveTransform
+    from normalizing_flows_amd import transforms as tr
     torch.manual_seed(5)
     for (D, H, K) in [(40, 64, 8), (300, 136, 4), (150, 256, 8)]:      # H < D-1, wrap-around degrees, H > D
         t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, num_bins=K, tails='linear',
@@ -309,13 +310,63 @@ def test_rq_ar_incremental_inverse_equals_d_pass_loop(nf, tol=1e-5):
             for p in t.parameters():
                 p.mul_(1.5)
             z = torch.randn(70, D, device='cuda') * 1.5
-            fast_x, fast_ld = t.inverse(z)
+            tr.ROW_RESIDENT_INVERSE = False          # (the row-resident kernel has its own test below)
+            try:
+                fast_x, fast_ld = t.inverse(z)
+            finally:
+                tr.ROW_RESIDENT_INVERSE = True
             slow_x, slow_ld = AutoregressiveTransform.inverse(t, z)
             back, ld_f = t(fast_x)
         assert len(t._feature_groups()) == min(D, H + 1 if H < D - 1 else D)
         assert (fast_x - slow_x).abs().max().item() < tol, (D, H, K)
         assert (fast_ld - slow_ld).abs().max().item() < 1e-4
         assert (back - z).abs().max().item() < 2e-3 and (ld_f + fast_ld).abs().max().item() < 5e-3
+
+
+ROW_CASES = [dict(D=100, H=64, K=8, B=70), dict(D=300, H=136, K=4, B=33), dict(D=784, H=512, K=8, B=45),
+             dict(D=65, H=64, K=8, B=32), dict(D=90, H=40, K=10, B=64, residual=False, blocks=3),
+             dict(D=90, H=48, K=5, B=31, blocks=1), dict(D=50, H=24, K=6, B=40, tails=None),
+             dict(D=40, H=16, K=8, B=1, residual=False, blocks=1)]
+
+
+@pytest.mark.parametrize('case', ROW_CASES, ids=lambda c: 'D%d_H%d_K%d' % (c['D'], c['H'], c['K']))
+def test_rq_ar_row_resident_inverse(nf, case, tol=3e-5):
+    """nf_made_rqs_inverse_rows (32 samples per workgroup from feature 0 to H in one launch) against the windowed
+    incremental inverse, which the test above ties to the reference's D-pass loop; plus the round trip.  The two
+    sum the hidden layers in different orders (rank-1 updates here, K-tiled MFMA there) and the difference feeds
+    forward through up to D features: 3e-5 absolute on outputs of magnitude ~4 (the fp64 parity of this path is
+    test_rq_ar_cfg3_golden's inverse leg)."""
+    from normalizing_flows_amd import transforms as tr
+    torch.manual_seed(7)
+    D, H, K, B = case['D'], case['H'], case['K'], case['B']
+    tails = case.get('tails', 'linear')
+    t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        D, H, num_bins=K, tails=tails, tail_bound=3., num_blocks=case.get('blocks', 2),
+        use_residual_blocks=case.get('residual', True)).cuda().eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+        z = torch.randn(B, D, device='cuda') * 1.5 if tails else torch.rand(B, D, device='cuda')
+        assert t.autoregressive_net.inverse_rows_pack(K, tails) is not None
+        fast_x, fast_ld = t.inverse(z)
+        tr.ROW_RESIDENT_INVERSE = False
+        try:
+            slow_x, slow_ld = t.inverse(z)
+        finally:
+            tr.ROW_RESIDENT_INVERSE = True
+        back, ld_f = t(fast_x)
+    assert (fast_x - slow_x).abs().max().item() < tol, case
+    assert (fast_ld - slow_ld).abs().max().item() < 1e-4 * max(1.0, slow_ld.abs().max().item() / 100)
+    assert (back - z).abs().max().item() < 2e-3 and (ld_f + fast_ld).abs().max().item() < 5e-3
+
+
+def test_rq_ar_row_resident_inverse_scope(nf):
+    """Networks the row-resident kernel does not cover keep the windowed path: wrap-around degrees, BatchNorm."""
+    mk = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform
+    assert mk(40, 64, num_bins=8, tails='linear').cuda().autoregressive_net.inverse_rows_pack(8, 'linear') is None
+    assert mk(100, 64, num_bins=8, tails='linear', use_batch_norm=True).cuda().eval() \
+        .autoregressive_net.inverse_rows_pack(8, 'linear') is None
+    assert mk(100, 64, num_bins=16, tails='linear').cuda().autoregressive_net.inverse_rows_pack(16, 'linear') is None
 
 
 # ------------------------------------------------------------------------------- bf16-MFMA mode
