@@ -245,6 +245,7 @@ int nf_made_rqs_inverse_rows_supported(int features, int hidden, int n_steps, in
  *   per hidden step s (initial layer, then each masked linear of the blocks, n_steps in all):
  *       WT[H][HS]: WT[j][k] = weight[k][j] * mask[k][j] (input j < H -> unit k), bias[HS]
  *   bf[H+1][32]: final-layer bias of feature f, parameters 0..P-1, zero padded
+ *   wl[H+1][32]: wl[f][c] = weight[f*P + c][f-1] * mask, the newest hidden unit feature f reads (wl[0] = 0)
  *   off[H+2 rounded up to 4] (int32 bit patterns): off[f] = sum over g < f of ceil(g / 8)
  *   wf[off[H+1]][64][4]: for feature f, K super-step S < ceil(f/8), lane (kh = lane>>5, col = lane&31):
  *       weight[f*P + col][8S + 4kh + 0..3] * mask (zero for col >= P) */

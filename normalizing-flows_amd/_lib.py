@@ -488,6 +488,10 @@ class PackedInverse:
         if final_bias is not None:
             bf[:, :P] = final_bias.detach().view(features, P)[:H + 1]
         parts.append(bf.reshape(-1))
+        wl = torch.zeros((H + 1, 32), dtype=torch.float32, device=dev)       # the newest unit each feature reads
+        idx = torch.arange(1, H + 1, device=dev)
+        wl[1:, :P] = wf[idx, :, idx - 1]
+        parts.append(wl.reshape(-1))
         nss = (torch.arange(H + 2, device=dev) + 7) // 8                  # super-steps of feature f
         off = torch.zeros((H + 2 + 3) // 4 * 4, dtype=torch.int32, device=dev)
         off[1:H + 2] = torch.cumsum(nss[:H + 1], 0).to(torch.int32)

@@ -40,7 +40,9 @@ constexpr int SS = 8;             // hidden units per K super-step of the final 
 #ifndef NF_INV_SLOTS
 #define NF_INV_SLOTS 2
 #endif
-constexpr int NB = NF_INV_SLOTS;  // B-operand register slots per wave (power of two)
+constexpr int NB = NF_INV_SLOTS;  // B-operand register slots per wave
+constexpr int MW = IW - 1;        // waves on the final-layer product (wave 0 inverts the spline meanwhile)
+constexpr int NI = (IT / SS + MW - 1) / MW;   // super-steps per wave at most
 
 constexpr int F_RELU_IN = 1, F_RESIDUAL = 2, F_RELU_OUT = 4;
 
@@ -55,6 +57,7 @@ struct InvArgs {
     const float* wt[MAXSTEP];     // [H][HS]: wt[s][j*HS + k] = weight (input j -> unit k), mask applied
     const float* bias[MAXSTEP];   // [HS]
     const float* bf;              // [H+1][32] final-layer bias of features 0..H, columns >= P zero
+    const float* wl;              // [H+1][32] wl[f][c] = W[f*P+c][f-1]: the newest hidden unit feature f reads
     const int32_t* off;           // [H+2] first super-step of each feature in wf
     const float4* wf;             // [super-step][lane]: lane (kh, col) holds W[f*P+col][8S+4kh .. +3]
     int flags[MAXSTEP];
@@ -67,8 +70,8 @@ template <int NSTEP, int KT>
 __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hlT = smem;                              // [HS][IR] final hidden state, unit-major
-    float* part = hlT + g.HS * IR;                  // [IW][IR][32] per-wave partial parameter tiles
-    float* prm = part + IW * IR * 32;               // [32][PSTR]
+    float* part = hlT + g.HS * IR;                  // [MW][IR][32] per-wave partial parameter tiles
+    float* prm = part + MW * IR * 32;               // [32][PSTR]
     float* bc = prm + 32 * PSTR;                    // [NSTEP][IR] broadcast slots
     float* xs = bc + MAXSTEP * IR;                  // [IR] the feature just inverted
 
@@ -100,82 +103,85 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 #pragma unroll
     for (int i = 0; i < NB; ++i) bw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int arow = lane & 31, kh = lane >> 5;
+    // parameters of feature 0: the bias alone
+    for (int e = tid; e < IR * 32; e += IT) prm[(e & 31) * PSTR + (e >> 5)] = g.bf[e & 31];
+    const int rc = tid & 31, rr = tid >> 5;     // parameter sums: this thread owns column rc of samples rr, rr + 16
+    float wl = g.wl[32 + rc], bfv = g.bf[32 + rc];
     __syncthreads();
 
-    for (int f = 0; f <= H; ++f) {
-        // ---- parameters of feature f: bias + hidden[0..f-1] x W_f, K split over the waves
-        const int NS = (f + SS - 1) / SS;
-        f32x16 d;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) d[i] = 0.0f;
-        const int64_t fo = g.off[f];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int S = wave + IW * i;
-            if (S < NS) {
-                const float* ap = hlT + (SS * S + 4 * kh) * IR + arow;
-                const float a0 = ap[0], a1 = ap[IR], a2 = ap[2 * IR], a3 = ap[3 * IR];
-                const float4 b = bw[i % NB];
-                // the slot's next user (NB super-steps of this wave later) is loaded behind these MFMAs
-                if (i + NB < 8 && S + NB * IW < NS) bw[i % NB] = g.wf[(fo + S + NB * IW) * 64 + lane];
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.z, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b.w, d, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
-            part[(wave * IR + r) * 32 + arow] = d[i];
-        }
-        __syncthreads();
-        for (int e = tid; e < IR * 32; e += IT) {
-            const int r = e >> 5, c = e & 31;
-            float v = g.bf[f * 32 + c];
-#pragma unroll
-            for (int w = 0; w < IW; ++w) v += part[(w * IR + r) * 32 + c];      // fixed order: deterministic
-            prm[c * PSTR + r] = v;
-        }
-        __syncthreads();
-        if (ev) {
-            float y, ld;
-            int bin;
-            #ifdef NF_NOEVAL
-            y = prm[tid] + znext; ld = prm[tid + PSTR]; bin = 0;
+#ifdef NF_INV_STAMP
+    long long st[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(i_) { const long long n_ = clock64(); st[i_] += n_ - tlast; tlast = n_; }
+    long long tlast = clock64();
 #else
-            typedef const __attribute__((address_space(3))) float* lds_ptr;
-            rqs_eval<KT, true, PSTR, false, false, lds_ptr>((lds_ptr)(prm + tid), znext, g.c, y, ld, bin);
+#define STAMP(i_)
 #endif
-            xs[tid] = y;
-            if (row_ok) g.x[row * g.ldx + f] = y;
-            ldsum += ld;
-            if ((f + 1) % g.fpt == 0) {
-                const int t = f / g.fpt;
-                if (row_ok && t < g.full_tiles) g.partial[(int64_t)t * g.B + row] = ldsum;
-                ldsum = 0.0f;
+    for (int f = 0; f <= H; ++f) {
+        if (wave == 0) {
+            // ---- wave 0: invert feature f (its parameters were completed at the end of the previous pass)
+            if (lane < IR) {
+                float y, ld;
+                int bin;
+#ifdef NF_NOEVAL
+                y = prm[tid] + znext; ld = prm[tid + PSTR]; bin = 0;
+#else
+                typedef const __attribute__((address_space(3))) float* lds_ptr;
+                rqs_eval<KT, true, PSTR, false, false, lds_ptr>((lds_ptr)(prm + tid), znext, g.c, y, ld, bin);
+#endif
+                xs[tid] = y;
+                if (row_ok) g.x[row * g.ldx + f] = y;
+                ldsum += ld;
+                if ((f + 1) % g.fpt == 0) {
+                    const int t = f / g.fpt;
+                    if (row_ok && t < g.full_tiles) g.partial[(int64_t)t * g.B + row] = ldsum;
+                    ldsum = 0.0f;
+                }
+                if (f < H) znext = g.z[row * g.ldz + f + 1];
             }
-            if (f < H) znext = g.z[row * g.ldz + f + 1];
+        } else if (f < H) {
+            // ---- waves 1..7 meanwhile: feature f+1 over the hidden units that are already final (0..f-1);
+            //      unit f, which this pass is about to finish, is added as a rank-1 term at the end
+            const int NS = (f + SS - 1) / SS;
+            f32x16 d;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+            const int64_t fo = g.off[f + 1];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int S = wave - 1 + MW * i;
+                if (S < NS) {
+                    const float* ap = hlT + (SS * S + 4 * kh) * IR + arow;
+                    const float a0 = ap[0], a1 = ap[IR], a2 = ap[2 * IR], a3 = ap[3 * IR];
+                    const float4 b = bw[i % NB];
+                    // the slot's next user (NB super-steps of this wave later) is loaded behind these MFMAs
+                    if (i + NB < NI && S + NB * MW < NS) bw[i % NB] = g.wf[(fo + S + NB * MW) * 64 + lane];
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.z, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b.w, d, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
+                part[((wave - 1) * IR + r) * 32 + arow] = d[i];
+            }
         }
+        STAMP(0)
         if (f == H) break;
 
-        // operands of the next feature: issued now, used a whole hidden chain later
-        {
+        // operands of the next pass: issued now, used a whole hidden chain later
+        if (wave > 0 && f + 1 < H) {
             const int NS1 = (f + SS) / SS;
-            const int64_t o = g.off[f + 1];
+            const int64_t o = g.off[f + 2];
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int S = wave + IW * i;
+                const int S = wave - 1 + MW * i;
                 if (S < NS1) bw[i] = g.wf[(o + S) * 64 + lane];
             }
         }
-        float wnext[NSTEP];
-        {
-            const int jn = f + 1 < H ? f + 1 : H - 1;
-#pragma unroll
-            for (int s = 0; s < NSTEP; ++s) wnext[s] = g.wt[s][(int64_t)jn * HS + kcol];
-        }
         __syncthreads();
+        STAMP(1)
 
         // ---- x[f] is known: unit j = f of every hidden layer becomes final, one layer after the other
         const int j = f;
@@ -187,6 +193,9 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 #pragma unroll
             for (int r = 0; r < IR / 2; ++r) acc[0][r] = __builtin_elementwise_fma(w2, v2[r], acc[0][r]);
         }
+        // (each weight register is reloaded for the next pass right after its use: a whole pass of latency cover)
+        const int64_t wrow = (int64_t)(f + 1 < H ? f + 1 : H - 1) * HS + kcol;
+        wcur[0] = g.wt[0][wrow];
 #pragma unroll
         for (int s = 1; s < NSTEP; ++s) {
             if (mine) {
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 #pragma unroll
                 for (int r = 0; r < IR / 2; ++r) acc[s][r] = __builtin_elementwise_fma(w2, v2[r], acc[s][r]);
             }
+            wcur[s] = g.wt[s][wrow];
             if (mine) {
                 if (s >= 2 && (g.flags[s] & F_RESIDUAL)) {
 #pragma unroll
@@ -225,10 +235,33 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 #pragma unroll
             for (int r = 0; r < IR / 2; ++r) o2[r] = acc[NSTEP - 1][r];
         }
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) wcur[s] = wnext[s];
+        STAMP(2)
         __syncthreads();
+        STAMP(3)
+
+        // ---- parameters of feature f+1: bias + the partial tiles (fixed order) + unit f's rank-1 term
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = rr + 16 * h;
+            float v = bfv;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) v += part[(w * IR + r) * 32 + rc];
+            prm[rc * PSTR + r] = fmaf(hlT[j * IR + r], wl, v);
+        }
+        {
+            const int fn = f + 2 <= H ? f + 2 : H;
+            wl = g.wl[fn * 32 + rc];
+            bfv = g.bf[fn * 32 + rc];
+        }
+        STAMP(4)
+        __syncthreads();
+        STAMP(5)
     }
+#ifdef NF_INV_STAMP
+    if (blockIdx.x == 0 && (tid & 63) == 0)
+        printf("wave %d: work %lld | barC %lld | chain %lld | barD %lld | reduce %lld | barB %lld (clock64 ticks per pass)\n", wave,
+               st[0] / H, st[1] / H, st[2] / H, st[3] / H, st[4] / H, st[5] / H);
+#endif
 
     // final hidden state for the features past H (one windowed launch of the fused layer kernel)
     if (unit) {
@@ -271,7 +304,7 @@ extern "C" int nf_made_rqs_inverse_rows_supported(int features, int hidden, int 
 extern "C" size_t nf_made_inverse_blob_floats(int hidden, int n_steps) {
     if (hidden <= 0 || hidden > IT || n_steps < 1 || n_steps > MAXSTEP) return 0;
     const size_t H = hidden, HS = hs_of(hidden);
-    return n_steps * (H + 1) * HS + (H + 1) * 32 + off_len(hidden) + (size_t)total_supersteps(hidden) * 256;
+    return n_steps * (H + 1) * HS + 2 * (H + 1) * 32 + off_len(hidden) + (size_t)total_supersteps(hidden) * 256;
 }
 
 extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags,
@@ -303,6 +336,7 @@ extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_ste
         }
     }
     g.bf = p; p += (size_t)(H + 1) * 32;
+    g.wl = p; p += (size_t)(H + 1) * 32;
     g.off = reinterpret_cast<const int32_t*>(p); p += off_len(H);
     g.wf = reinterpret_cast<const float4*>(p);
     g.z = z; g.ldz = z_row_stride; g.x = x; g.ldx = x_row_stride; g.hid = hidden_out; g.ldh = h_row_stride;
@@ -310,7 +344,7 @@ extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_ste
     g.full_tiles = (H + 1) / g.fpt;
     const int64_t grid = (B + IR - 1) / IR;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    const size_t lds = sizeof(float) * ((size_t)HS * IR + IW * IR * 32 + 32 * PSTR + MAXSTEP * IR + IR);
+    const size_t lds = sizeof(float) * ((size_t)HS * IR + MW * IR * 32 + 32 * PSTR + MAXSTEP * IR + IR);
     hipStream_t st = (hipStream_t)stream;
     switch (n_steps) {
         case 2: return launch_steps<2>(g, K, (unsigned)grid, lds, st);
