@@ -245,10 +245,13 @@ int nf_made_rqs_inverse_rows_supported(int features, int hidden, int n_steps, in
  *   per hidden step s (initial layer, then each masked linear of the blocks, n_steps in all):
  *       WT[H][HS]: WT[j][k] = weight[k][j] * mask[k][j] (input j < H -> unit k), bias[HS]
  *   bf[H+1][32]: final-layer bias of feature f, parameters 0..P-1, zero padded
- *   wl[H+1][32]: wl[f][c] = weight[f*P + c][f-1] * mask, the newest hidden unit feature f reads (wl[0] = 0)
+ *   wl[H+1][2][32]: wl[f][0][c] = weight[f*P + c][f-1] * mask, wl[f][1][c] = weight[f*P + c][f-2] * mask: the two
+ *       newest hidden units feature f reads (zero where there is none)
+ *   dg[H][16]: unit j of hidden step s: dg[j][s] = its weight on unit j of step s-1 (s = 0: on input j),
+ *       dg[j][8 + s] = its weight on unit j-1 (zero for j = 0), mask applied
  *   off[H+2 rounded up to 4] (int32 bit patterns): off[f] = sum over g < f of ceil(g / 8)
  *   wf[off[H+1]][64][4]: for feature f, K super-step S < ceil(f/8), lane (kh = lane>>5, col = lane&31):
- *       weight[f*P + col][8S + 4kh + 0..3] * mask (zero for col >= P) */
+ *       weight[f*P + col][8S + 4kh + 0..3] * mask (zero for col >= P and for the units f-2, f-1 kept in wl) */
 size_t nf_made_inverse_blob_floats(int hidden, int n_steps);
 /* x[b, 0..hidden] = inverse of z[b, 0..hidden] feature by feature; hidden_out[b, :] = final hidden state;
  * workspace = the [tiles][B] logdet partials of nf_made_rqs_fwd_tiles (tiles wholly below feature hidden+1

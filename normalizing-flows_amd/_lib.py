@@ -488,10 +488,21 @@ class PackedInverse:
         if final_bias is not None:
             bf[:, :P] = final_bias.detach().view(features, P)[:H + 1]
         parts.append(bf.reshape(-1))
-        wl = torch.zeros((H + 1, 32), dtype=torch.float32, device=dev)       # the newest unit each feature reads
+        # the two newest units each feature reads join as rank-1 terms: wl[f][0][c] = W[f*P+c][f-1], [1]: [f-2]
+        wl = torch.zeros((H + 1, 2, 32), dtype=torch.float32, device=dev)
         idx = torch.arange(1, H + 1, device=dev)
-        wl[1:, :P] = wf[idx, :, idx - 1]
+        wl[1:, 0, :P] = wf[idx, :, idx - 1]
+        wl[2:, 1, :P] = wf[idx[1:], :, idx[1:] - 2]
         parts.append(wl.reshape(-1))
+        # hidden layers, unit j: dg[j][s] = step s's weight on unit j of the step before (s = 0: on input j),
+        # dg[j][8 + s] = its weight on unit j-1
+        dg = torch.zeros((H, 16), dtype=torch.float32, device=dev)
+        ar = torch.arange(H, device=dev)
+        for s, (w, m, b, fl) in enumerate(steps):
+            wm = w.detach() if m is None else w.detach() * m
+            dg[:, s] = wm[ar, ar]
+            dg[1:, 8 + s] = wm[ar[1:], ar[:-1]]
+        parts.append(dg.reshape(-1))
         nss = (torch.arange(H + 2, device=dev) + 7) // 8                  # super-steps of feature f
         off = torch.zeros((H + 2 + 3) // 4 * 4, dtype=torch.int32, device=dev)
         off[1:H + 2] = torch.cumsum(nss[:H + 1], 0).to(torch.int32)
@@ -499,6 +510,8 @@ class PackedInverse:
         ns_max = (H + 7) // 8
         dense = torch.zeros((H + 1, 32, ns_max * 8), dtype=torch.float32, device=dev)
         dense[:, :P, :H] = wf
+        fi = torch.arange(H + 1, device=dev)[:, None, None]
+        dense[(torch.arange(ns_max * 8, device=dev)[None, None, :] >= fi - 2).expand_as(dense)] = 0.0   # (rank-1 terms)
         dense = dense.view(H + 1, 32, ns_max, 2, 4).permute(0, 2, 3, 1, 4)         # [f][S][kh][col][4]
         live = torch.arange(ns_max, device=dev)[None, :] < nss[:H + 1, None]
         parts.append(dense[live].reshape(-1))

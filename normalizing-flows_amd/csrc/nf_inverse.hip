@@ -6,18 +6,21 @@
 // reads hidden units 0..f-1 only, and input f reaches unit k only for k >= f.  So once x[f] is known
 //   * unit f of every hidden layer becomes final (nothing later can change it), and
 //   * the parameters of feature f+1 are one 32-column row block of the final layer over units 0..f.
-// The samples never interact, so a workgroup keeps 32 samples from x[0] to x[H] without any grid-wide step:
+// The samples never interact, so a workgroup keeps 32 samples from x[0] to x[H] without any grid-wide step,
+// as a software pipeline with ONE barrier per feature ("round" j = feature j / unit j):
 //
-//   hidden layers, "right-looking": thread k owns unit k of every hidden layer and keeps its running
-//     pre-activation for all 32 samples in registers (NSTEP x 32 fp32).  When unit j becomes final its
-//     activation (32 values) is broadcast through LDS and every thread adds its one weight times it.
-//     Per feature and layer: one 2 KB weight row (transposed pack, coalesced, prefetched a pass ahead),
-//     32 FMAs per thread, one barrier.  Total = the masked MACs of one forward pass.
-//   final layer, "left-looking": the final hidden state so far lives in LDS ([unit][sample]); the P <= 32
-//     parameter columns of feature f+1 are a 32 x 32 x f product on v_mfma_f32_32x32x2_f32, K split over the
-//     8 waves (weights packed per feature in operand order, triangular: only the live K range is stored
-//     and read), partial tiles summed in fixed order through LDS, then 32 lanes invert the spline
-//     (nf_rqs_eval.h, the code the forward kernels use) and broadcast x[f+1].
+//   wave 0, lanes = samples (the critical path): completes the parameters of feature j (bulk part from LDS +
+//     the rank-1 terms of the two newest hidden units), inverts the spline (nf_rqs_eval.h, the code the forward
+//     kernels use), then finishes unit j of every hidden layer for its sample - a chain of NSTEP scalar FMAs,
+//     because everything older than unit j-1 is already summed in a partial that unit j's owner exported a
+//     round earlier - and publishes x[j], unit j's activations and its final hidden value through LDS.
+//   all threads, one round behind (thread k owns unit k of every hidden layer: NSTEP x 32 running sums in
+//     registers, "right-looking"): add unit j-1's activations times one weight each (transposed pack: a 2 KB
+//     coalesced weight row per layer and round, reloaded a round ahead); thread j+1 exports its sums.
+//   waves 1..7, "left-looking": the final-layer row block of feature j+2 over hidden units 0..j-1, a
+//     32 x 32 x j product on v_mfma_f32_32x32x2_f32 with K split over the waves (weights packed per feature in
+//     operand order, triangular: only the live K range is stored and read); the partial tiles of the
+//     previous round are summed in fixed order into the bulk parameters wave 0 reads next round.
 //
 // Features past H+1 depend on no further hidden unit: the kernel leaves the final hidden state in HBM and
 // the caller finishes them with one windowed launch of the fused layer kernel (nf_made_rqs_fwd_tiles).
@@ -35,14 +38,12 @@ constexpr int IR = 32;            // samples per workgroup
 constexpr int IT = 512;           // threads = hidden units a workgroup can own
 constexpr int IW = IT / 64;
 constexpr int MAXSTEP = 5;        // hidden vectors: initial layer + 2 per residual block (1 per feed-forward block)
-constexpr int PSTR = 33;          // stride of the parameter tile [column][sample]
+constexpr int PSTR = 33;          // stride of the parameter tiles [column][sample]
 constexpr int SS = 8;             // hidden units per K super-step of the final layer (4 MFMAs of K = 2)
-#ifndef NF_INV_SLOTS
-#define NF_INV_SLOTS 2
-#endif
-constexpr int NB = NF_INV_SLOTS;  // B-operand register slots per wave
+constexpr int NQ = 6;             // B-operand register slots per wave (loaded at the top of a round, reused in place)
 constexpr int MW = IW - 1;        // waves on the final-layer product (wave 0 inverts the spline meanwhile)
 constexpr int NI = (IT / SS + MW - 1) / MW;   // super-steps per wave at most
+constexpr int NRED = (IR * 32 + MW * 64 - 1) / (MW * 64);   // parameter sums per thread of waves 1..7
 
 constexpr int F_RELU_IN = 1, F_RESIDUAL = 2, F_RELU_OUT = 4;
 
@@ -57,9 +58,10 @@ struct InvArgs {
     const float* wt[MAXSTEP];     // [H][HS]: wt[s][j*HS + k] = weight (input j -> unit k), mask applied
     const float* bias[MAXSTEP];   // [HS]
     const float* bf;              // [H+1][32] final-layer bias of features 0..H, columns >= P zero
-    const float* wl;              // [H+1][32] wl[f][c] = W[f*P+c][f-1]: the newest hidden unit feature f reads
+    const float* wl;              // [H+1][2][32] wl[f][0][c] = W[f*P+c][f-1], wl[f][1][c] = W[f*P+c][f-2]
+    const float* dg;              // [H][16] unit j: [s] = step s's weight on unit j of the step before, [8+s] = on unit j-1
     const int32_t* off;           // [H+2] first super-step of each feature in wf
-    const float4* wf;             // [super-step][lane]: lane (kh, col) holds W[f*P+col][8S+4kh .. +3]
+    const float4* wf;             // [super-step][lane]: lane (kh, col) holds W[f*P+col][8S+4kh .. +3], units >= f-2 zeroed
     int flags[MAXSTEP];
     int64_t B;
     int H, HS, fpt, full_tiles;
@@ -70,10 +72,11 @@ template <int NSTEP, int KT>
 __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hlT = smem;                              // [HS][IR] final hidden state, unit-major
-    float* part = hlT + g.HS * IR;                  // [MW][IR][32] per-wave partial parameter tiles
-    float* prm = part + MW * IR * 32;               // [32][PSTR]
-    float* bc = prm + 32 * PSTR;                    // [NSTEP][IR] broadcast slots
-    float* xs = bc + MAXSTEP * IR;                  // [IR] the feature just inverted
+    float* part = hlT + g.HS * IR;                  // [2][MW][IR][32] per-wave partial parameter tiles, by feature parity
+    float* prmb = part + 2 * MW * IR * 32;          // [2][32][PSTR] bulk parameters, by feature parity
+    float* prm = prmb + 2 * 32 * PSTR;              // [32][PSTR] wave 0's completed parameters
+    float* bc = prm + 32 * PSTR;                    // [2][MAXSTEP][IR] activations of the unit just finished, by parity
+    float* sh = bc + 2 * MAXSTEP * IR;              // [2][MAXSTEP][IR] exported running sums of the next unit, by parity
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * IR;
@@ -89,187 +92,219 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
         for (int r = 0; r < IR / 2; ++r) acc[s][r] = (f32x2){b, b};
     }
     for (int e = tid; e < HS * IR; e += IT) hlT[e] = 0.0f;
+    for (int e = tid; e < 2 * MW * IR * 32; e += IT) part[e] = 0.0f;
+    for (int e = tid; e < IR * 32; e += IT) prmb[(e & 31) * PSTR + (e >> 5)] = g.bf[e & 31];   // feature 0: bias alone
+    if (tid == 0) {                                 // unit 0's running sums: nothing precedes it
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+            for (int r = 0; r < IR / 2; ++r) reinterpret_cast<f32x2*>(sh + s * IR)[r] = acc[s][r];
+    }
 
-    const bool ev = tid < IR;
-    const int64_t row = (m0 + tid < g.B) ? m0 + tid : g.B - 1;
-    const bool row_ok = ev && m0 + tid < g.B;
-    float znext = ev ? g.z[row * g.ldz] : 0.0f;
-    float ldsum = 0.0f;
+    // Per-role state in one register array (wave 0 never runs the bulk product, the others never invert splines):
+    //   wave 0:     rs[0..NSTEP) = activations of the unit finished last round, rs[5] = next unit's weight record,
+    //               rs[6] = final hidden value of unit j-1, rs[7] = next input z, rs[8] = running logdet sum,
+    //               rs[9] = next feature's two newest-unit weight rows (lane = [row][column])
+    //   waves 1..7: rs[8] = next bias
+    float rs[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) rs[i] = 0.0f;
+    if (wave == 0) {
+        rs[7] = tid < IR ? g.z[((m0 + tid < g.B) ? m0 + tid : g.B - 1) * g.ldz] : 0.0f;
+        rs[5] = g.dg[tid & 15];
+        rs[9] = g.wl[lane];
+    } else {
+        rs[8] = g.bf[32 + (tid & 31)];      // parameter sums (waves 1..7): column tid & 31 of NRED samples
+    }
 
     float wcur[NSTEP];
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) wcur[s] = g.wt[s][kcol];
-    float4 bw[NB];                // B operands of this wave's first NB super-steps (the rest follow in place)
-#pragma unroll
-    for (int i = 0; i < NB; ++i) bw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int arow = lane & 31, kh = lane >> 5;
-    // parameters of feature 0: the bias alone
-    for (int e = tid; e < IR * 32; e += IT) prm[(e & 31) * PSTR + (e >> 5)] = g.bf[e & 31];
-    const int rc = tid & 31, rr = tid >> 5;     // parameter sums: this thread owns column rc of samples rr, rr + 16
-    float wl = g.wl[32 + rc], bfv = g.bf[32 + rc];
     __syncthreads();
 
 #ifdef NF_INV_STAMP
-    long long st[6] = {0, 0, 0, 0, 0, 0};
-#define STAMP(i_) { const long long n_ = clock64(); st[i_] += n_ - tlast; tlast = n_; }
-    long long tlast = clock64();
+    // phase timing: per-wave cycle sums in LDS (registers are all spoken for)
+    unsigned* stamps = reinterpret_cast<unsigned*>(sh + 2 * MAXSTEP * IR);
+    if (threadIdx.x < IW * 8) stamps[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned tlast = (unsigned)clock64();
+#define STAMP(i_) { const unsigned n_ = (unsigned)clock64(); if ((threadIdx.x & 63) == 0) stamps[wave * 8 + i_] += n_ - tlast; tlast = n_; }
 #else
 #define STAMP(i_)
 #endif
-    for (int f = 0; f <= H; ++f) {
+    for (int j = 0; j <= H; ++j) {
+        const int par = j & 1;
+        // Everything derived from the thread index is recomputed per round from an opaque copy: hoisted out of the
+        // loop those values (addresses, row numbers) stay live across the spline inversion, the point of highest
+        // register pressure, and were spilled to scratch - with a scratch reload in front of every MFMA group.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, arow = tid & 31, kh = (tid >> 5) & 1, rc = tid & 31;
+        const int kcol = tid < H ? tid : 0;
         if (wave == 0) {
-            // ---- wave 0: invert feature f (its parameters were completed at the end of the previous pass)
+            // ---- the critical path: feature j and hidden unit j
+            // parameters of feature j = bulk (units <= j-3) + [h(j-1) h(j-2)] x their two weight rows: one
+            // 32 x 32 x 2 MFMA on the bulk tile (lanes 0..31 hold h(j-1) of their sample, lanes 32..63 fetch h(j-2))
+            {
+                const float a = lane < IR ? rs[6] : (j >= 2 ? hlT[(j - 2) * IR + arow] : 0.0f);
+                const float* pb = prmb + (par * 32 + arow) * PSTR + 4 * kh;
+                f32x16 c;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) c[i] = pb[(i & 3) + 8 * (i >> 2)];
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rs[9], c, 0, 0, 0);
+                float* po = prm + arow * PSTR + 4 * kh;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) po[(i & 3) + 8 * (i >> 2)] = c[i];
+                rs[9] = g.wl[(int64_t)(j < H ? j + 1 : H) * 64 + lane];      // next round's weight rows
+            }
+            STAMP(0)
             if (lane < IR) {
+                const int64_t row = (m0 + tid < g.B) ? m0 + tid : g.B - 1;
+                const bool row_ok = m0 + tid < g.B;
                 float y, ld;
                 int bin;
 #ifdef NF_NOEVAL
-                y = prm[tid] + znext; ld = prm[tid + PSTR]; bin = 0;
+                y = prm[tid] + rs[7]; ld = prm[tid + PSTR]; bin = 0;
 #else
                 typedef const __attribute__((address_space(3))) float* lds_ptr;
-                rqs_eval<KT, true, PSTR, false, false, lds_ptr>((lds_ptr)(prm + tid), znext, g.c, y, ld, bin);
+                rqs_eval<KT, true, PSTR, false, false, lds_ptr>((lds_ptr)(prm + tid), rs[7], g.c, y, ld, bin);
 #endif
-                xs[tid] = y;
-                if (row_ok) g.x[row * g.ldx + f] = y;
-                ldsum += ld;
-                if ((f + 1) % g.fpt == 0) {
-                    const int t = f / g.fpt;
-                    if (row_ok && t < g.full_tiles) g.partial[(int64_t)t * g.B + row] = ldsum;
-                    ldsum = 0.0f;
+                if (row_ok) g.x[row * g.ldx + j] = y;
+                rs[8] += ld;
+                if ((j + 1) % g.fpt == 0) {
+                    const int t = j / g.fpt;
+                    if (row_ok && t < g.full_tiles) g.partial[(int64_t)t * g.B + row] = rs[8];
+                    rs[8] = 0.0f;
                 }
-                if (f < H) znext = g.z[row * g.ldz + f + 1];
-            }
-        } else if (f < H) {
-            // ---- waves 1..7 meanwhile: feature f+1 over the hidden units that are already final (0..f-1);
-            //      unit f, which this pass is about to finish, is added as a rank-1 term at the end
-            const int NS = (f + SS - 1) / SS;
-            f32x16 d;
+                STAMP(1)
+                if (j < H) {
+                    rs[7] = g.z[row * g.ldz + j + 1];
+                    // unit j's weights on itself (lanes 0..7 of the record) and on unit j-1 (lanes 8..15), one per step
+                    const int rec = __float_as_int(rs[5]);
+                    // running sums of unit j: its owner's export (units <= j-2) + unit j-1's term
+                    float cur[NSTEP];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = 0.0f;
-            const int64_t fo = g.off[f + 1];
+                    for (int s = 0; s < NSTEP; ++s)
+                        cur[s] = fmaf(__int_as_float(__builtin_amdgcn_readlane(rec, 8 + s)), rs[s],
+                                      sh[(par * MAXSTEP + s) * IR + tid]);
+                    // unit j of every hidden layer, one layer after the other
+                    float val[NSTEP];
+                    rs[0] = y;
+                    val[0] = fmaf(__int_as_float(__builtin_amdgcn_readlane(rec, 0)), y, cur[0]);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int S = wave - 1 + MW * i;
-                if (S < NS) {
-                    const float* ap = hlT + (SS * S + 4 * kh) * IR + arow;
-                    const float a0 = ap[0], a1 = ap[IR], a2 = ap[2 * IR], a3 = ap[3 * IR];
-                    const float4 b = bw[i % NB];
-                    // the slot's next user (NB super-steps of this wave later) is loaded behind these MFMAs
-                    if (i + NB < NI && S + NB * MW < NS) bw[i % NB] = g.wf[(fo + S + NB * MW) * 64 + lane];
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.z, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b.w, d, 0, 0, 0);
+                    for (int s = 1; s < NSTEP; ++s) {
+                        rs[s] = (g.flags[s] & F_RELU_IN) ? fmaxf(val[s - 1], 0.0f) : val[s - 1];
+                        val[s] = fmaf(__int_as_float(__builtin_amdgcn_readlane(rec, s)), rs[s], cur[s]);
+                        if (s >= 2 && (g.flags[s] & F_RESIDUAL)) val[s] += val[s >= 2 ? s - 2 : 0];
+                        if (g.flags[s] & F_RELU_OUT) val[s] = fmaxf(val[s], 0.0f);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NSTEP; ++s) bc[(par * MAXSTEP + s) * IR + tid] = rs[s];
+                    hlT[j * IR + tid] = val[NSTEP - 1];
+                    rs[6] = val[NSTEP - 1];
+                    rs[5] = g.dg[(int64_t)(j + 1 < H ? j + 1 : H - 1) * 16 + (tid & 15)];
                 }
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
-                part[((wave - 1) * IR + r) * 32 + arow] = d[i];
+                STAMP(2)
             }
         }
-        STAMP(0)
-        if (f == H) break;
+        if (j == H) break;
 
-        // operands of the next pass: issued now, used a whole hidden chain later
-        if (wave > 0 && f + 1 < H) {
-            const int NS1 = (f + SS) / SS;
-            const int64_t o = g.off[f + 2];
+        // ---- waves 1..7: the B operands of this round's product first, the update below covers their latency
+        const int NS = (j + SS - 1) / SS;
+        const int64_t fo = g.off[j + 2 <= H ? j + 2 : H];
+        float4 bq[NQ];
+        if (wave > 0 && j + 2 <= H) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
+            for (int i = 0; i < NQ; ++i) {
                 const int S = wave - 1 + MW * i;
-                if (S < NS1) bw[i] = g.wf[(o + S) * 64 + lane];
+                if (S < NS) bq[i] = g.wf[(fo + S) * 64 + lane];
             }
         }
-        __syncthreads();
-        STAMP(1)
 
-        // ---- x[f] is known: unit j = f of every hidden layer becomes final, one layer after the other
-        const int j = f;
-        const bool live = wave * 64 + 63 >= j;          // units below j are final: their weights are masked
-        const bool mine = tid == j;
-        if (live) {
-            const f32x2 w2 = (f32x2){wcur[0], wcur[0]};
-            const f32x2* v2 = reinterpret_cast<const f32x2*>(xs);
+        // ---- everyone, one round behind: unit j-1's activations into the running sums of the units after it
+        if (j > 0 && wave * 64 + 63 > j) {              // units <= j are finished or being finished by wave 0
+            const float* b = bc + ((par ^ 1) * MAXSTEP) * IR;
 #pragma unroll
-            for (int r = 0; r < IR / 2; ++r) acc[0][r] = __builtin_elementwise_fma(w2, v2[r], acc[0][r]);
-        }
-        // (each weight register is reloaded for the next pass right after its use: a whole pass of latency cover)
-        const int64_t wrow = (int64_t)(f + 1 < H ? f + 1 : H - 1) * HS + kcol;
-        wcur[0] = g.wt[0][wrow];
-#pragma unroll
-        for (int s = 1; s < NSTEP; ++s) {
-            if (mine) {
-                f32x2* o2 = reinterpret_cast<f32x2*>(bc + s * IR);
-                const bool relu = g.flags[s] & F_RELU_IN;
-#pragma unroll
-                for (int r = 0; r < IR / 2; ++r) {
-                    f32x2 v = acc[s - 1][r];
-                    if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); }
-                    o2[r] = v;
-                }
-            }
-            __syncthreads();
-            if (live) {
+            for (int s = 0; s < NSTEP; ++s) {
                 const f32x2 w2 = (f32x2){wcur[s], wcur[s]};
-                const f32x2* v2 = reinterpret_cast<const f32x2*>(bc + s * IR);
+                const f32x2* v2 = reinterpret_cast<const f32x2*>(b + s * IR);
 #pragma unroll
                 for (int r = 0; r < IR / 2; ++r) acc[s][r] = __builtin_elementwise_fma(w2, v2[r], acc[s][r]);
             }
-            wcur[s] = g.wt[s][wrow];
-            if (mine) {
-                if (s >= 2 && (g.flags[s] & F_RESIDUAL)) {
-#pragma unroll
-                    for (int r = 0; r < IR / 2; ++r) acc[s][r] = acc[s][r] + acc[s >= 2 ? s - 2 : 0][r];
-                }
-                if (g.flags[s] & F_RELU_OUT) {
-#pragma unroll
-                    for (int r = 0; r < IR / 2; ++r) {
-                        acc[s][r].x = fmaxf(acc[s][r].x, 0.0f);
-                        acc[s][r].y = fmaxf(acc[s][r].y, 0.0f);
-                    }
-                }
-            }
-        }
-        if (mine) {
-            f32x2* o2 = reinterpret_cast<f32x2*>(hlT + j * IR);
-#pragma unroll
-            for (int r = 0; r < IR / 2; ++r) o2[r] = acc[NSTEP - 1][r];
-        }
-        STAMP(2)
-        __syncthreads();
-        STAMP(3)
-
-        // ---- parameters of feature f+1: bias + the partial tiles (fixed order) + unit f's rank-1 term
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = rr + 16 * h;
-            float v = bfv;
-#pragma unroll
-            for (int w = 0; w < MW; ++w) v += part[(w * IR + r) * 32 + rc];
-            prm[rc * PSTR + r] = fmaf(hlT[j * IR + r], wl, v);
         }
         {
-            const int fn = f + 2 <= H ? f + 2 : H;
-            wl = g.wl[fn * 32 + rc];
-            bfv = g.bf[fn * 32 + rc];
+            // (each weight register is reloaded for the next round right after its use)
+            const int64_t wrow = (int64_t)(j < H ? j : H - 1) * HS + kcol;
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) wcur[s] = g.wt[s][wrow];
         }
-        STAMP(4)
-        __syncthreads();
+        if (tid == j + 1) {                             // unit j+1's sums over units <= j-1, for wave 0's next round
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+                for (int r = 0; r < IR / 2; ++r) reinterpret_cast<f32x2*>(sh + ((par ^ 1) * MAXSTEP + s) * IR)[r] = acc[s][r];
+        }
+        STAMP(3)
+        if (wave > 0) {
+            // ---- feature j+2 over the hidden units 0..j-1 (units j, j+1 join as rank-1 terms in wave 0)
+            if (j + 2 <= H) {
+                f32x16 d;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int S = wave - 1 + MW * i;
+                    if (S < NS) {
+                        const float* ap = hlT + (SS * S + 4 * kh) * IR + arow;
+                        const float a0 = ap[0], a1 = ap[IR], a2 = ap[2 * IR], a3 = ap[3 * IR];
+                        const float4 b = bq[i % NQ];
+                        // the slot's next user (NQ super-steps of this wave later) is loaded behind these MFMAs
+                        if (i + NQ < NI && S + NQ * MW < NS) bq[i % NQ] = g.wf[(fo + S + NQ * MW) * 64 + lane];
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.z, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b.w, d, 0, 0, 0);
+                    }
+                }
+                float* pt = part + (par * MW + wave - 1) * IR * 32;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
+                    pt[r * 32 + arow] = d[i];
+                }
+            }
+            STAMP(4)
+            // ---- bulk parameters of feature j+1: bias + last round's partial tiles, fixed order
+            const float* pp = part + (par ^ 1) * MW * IR * 32;
+            float* po = prmb + (par ^ 1) * 32 * PSTR;
+#pragma unroll
+            for (int h = 0; h < NRED; ++h) {
+                const int r = ((tid - 64) >> 5) + (MW * 2) * h;
+                if (r < IR) {
+                    float s = rs[8];
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) s += pp[(w * IR + r) * 32 + rc];
+                    po[rc * PSTR + r] = s;
+                }
+            }
+            rs[8] = g.bf[(j + 2 <= H ? j + 2 : H) * 32 + rc];
+        }
         STAMP(5)
+        __syncthreads();
+        STAMP(6)
     }
 #ifdef NF_INV_STAMP
-    if (blockIdx.x == 0 && (tid & 63) == 0)
-        printf("wave %d: work %lld | barC %lld | chain %lld | barD %lld | reduce %lld | barB %lld (clock64 ticks per pass)\n", wave,
-               st[0] / H, st[1] / H, st[2] / H, st[3] / H, st[4] / H, st[5] / H);
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+        printf("wave %d: params %u | eval %u | unit %u | update %u | mfma %u | sums %u | barrier %u (cycles per round)\n", wave,
+               stamps[wave * 8] / H, stamps[wave * 8 + 1] / H, stamps[wave * 8 + 2] / H, stamps[wave * 8 + 3] / H,
+               stamps[wave * 8 + 4] / H, stamps[wave * 8 + 5] / H, stamps[wave * 8 + 6] / H);
 #endif
 
     // final hidden state for the features past H (one windowed launch of the fused layer kernel)
+    __syncthreads();
     if (unit) {
-#pragma unroll
-        for (int r = 0; r < IR / 2; ++r) {
-            if (m0 + 2 * r < g.B) g.hid[(m0 + 2 * r) * g.ldh + tid] = acc[NSTEP - 1][r].x;
-            if (m0 + 2 * r + 1 < g.B) g.hid[(m0 + 2 * r + 1) * g.ldh + tid] = acc[NSTEP - 1][r].y;
-        }
+        for (int r = 0; r < IR; ++r)
+            if (m0 + r < g.B) g.hid[(m0 + r) * g.ldh + tid] = hlT[tid * IR + r];
     }
 }
 
@@ -304,7 +339,7 @@ extern "C" int nf_made_rqs_inverse_rows_supported(int features, int hidden, int 
 extern "C" size_t nf_made_inverse_blob_floats(int hidden, int n_steps) {
     if (hidden <= 0 || hidden > IT || n_steps < 1 || n_steps > MAXSTEP) return 0;
     const size_t H = hidden, HS = hs_of(hidden);
-    return n_steps * (H + 1) * HS + 2 * (H + 1) * 32 + off_len(hidden) + (size_t)total_supersteps(hidden) * 256;
+    return n_steps * (H + 1) * HS + 3 * (H + 1) * 32 + H * 16 + off_len(hidden) + (size_t)total_supersteps(hidden) * 256;
 }
 
 extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags,
@@ -336,7 +371,8 @@ extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_ste
         }
     }
     g.bf = p; p += (size_t)(H + 1) * 32;
-    g.wl = p; p += (size_t)(H + 1) * 32;
+    g.wl = p; p += (size_t)(H + 1) * 64;
+    g.dg = p; p += (size_t)H * 16;
     g.off = reinterpret_cast<const int32_t*>(p); p += off_len(H);
     g.wf = reinterpret_cast<const float4*>(p);
     g.z = z; g.ldz = z_row_stride; g.x = x; g.ldx = x_row_stride; g.hid = hidden_out; g.ldh = h_row_stride;
@@ -344,7 +380,7 @@ extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_ste
     g.full_tiles = (H + 1) / g.fpt;
     const int64_t grid = (B + IR - 1) / IR;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    const size_t lds = sizeof(float) * ((size_t)HS * IR + MW * IR * 32 + 32 * PSTR + MAXSTEP * IR + IR);
+    const size_t lds = sizeof(float) * ((size_t)HS * IR + 2 * MW * IR * 32 + 3 * 32 * PSTR + 4 * MAXSTEP * IR + IW * 8);
     hipStream_t st = (hipStream_t)stream;
     switch (n_steps) {
         case 2: return launch_steps<2>(g, K, (unsigned)grid, lds, st);

@@ -356,7 +356,7 @@ def test_rq_ar_row_resident_inverse(nf, case, tol=3e-5):
             tr.ROW_RESIDENT_INVERSE = True
         back, ld_f = t(fast_x)
     assert (fast_x - slow_x).abs().max().item() < tol, case
-    assert (fast_ld - slow_ld).abs().max().item() < 1e-4 * max(1.0, slow_ld.abs().max().item() / 100)
+    assert (fast_ld - slow_ld).abs().max().item() < 1e-4 + 3e-6 * slow_ld.abs().max().item()      # fp32 sums of ~D terms
     assert (back - z).abs().max().item() < 2e-3 and (ld_f + fast_ld).abs().max().item() < 5e-3
 
 
