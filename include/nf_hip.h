@@ -249,8 +249,8 @@ int nf_made_rqs_inverse_rows_supported(int features, int hidden, int n_steps, in
  *       newest hidden units feature f reads (zero where there is none)
  *   dg[H][16]: unit j of hidden step s: dg[j][s] = its weight on unit j of step s-1 (s = 0: on input j),
  *       dg[j][8 + s] = its weight on unit j-1 (zero for j = 0), mask applied
- *   off[H+2 rounded up to 4] (int32 bit patterns): off[f] = sum over g < f of ceil(g / 8)
- *   wf[off[H+1]][64][4]: for feature f, K super-step S < ceil(f/8), lane (kh = lane>>5, col = lane&31):
+ *   wf[T][64][4], features 0..H back to back (feature f starts at super-step sum over g < f of ceil(g/8)):
+ *       for feature f, K super-step S < ceil(f/8), lane (kh = lane>>5, col = lane&31):
  *       weight[f*P + col][8S + 4kh + 0..3] * mask (zero for col >= P and for the units f-2, f-1 kept in wl) */
 size_t nf_made_inverse_blob_floats(int hidden, int n_steps);
 /* x[b, 0..hidden] = inverse of z[b, 0..hidden] feature by feature; hidden_out[b, :] = final hidden state;

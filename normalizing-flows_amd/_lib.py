@@ -504,9 +504,6 @@ class PackedInverse:
             dg[1:, 8 + s] = wm[ar[1:], ar[:-1]]
         parts.append(dg.reshape(-1))
         nss = (torch.arange(H + 2, device=dev) + 7) // 8                  # super-steps of feature f
-        off = torch.zeros((H + 2 + 3) // 4 * 4, dtype=torch.int32, device=dev)
-        off[1:H + 2] = torch.cumsum(nss[:H + 1], 0).to(torch.int32)
-        parts.append(off.view(torch.float32))
         ns_max = (H + 7) // 8
         dense = torch.zeros((H + 1, 32, ns_max * 8), dtype=torch.float32, device=dev)
         dense[:, :P, :H] = wf

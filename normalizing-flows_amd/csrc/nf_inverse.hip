@@ -40,12 +40,19 @@ constexpr int IW = IT / 64;
 constexpr int MAXSTEP = 5;        // hidden vectors: initial layer + 2 per residual block (1 per feed-forward block)
 constexpr int PSTR = 33;          // stride of the parameter tiles [column][sample]
 constexpr int SS = 8;             // hidden units per K super-step of the final layer (4 MFMAs of K = 2)
-constexpr int NQ = 6;             // B-operand register slots per wave (loaded at the top of a round, reused in place)
+constexpr int NP = 2;             // B-operand slots loaded a round ahead (kept in rs[4..12) across the barrier)
+constexpr int NQ = 4;             // B-operand slots loaded at the top of the round and reused in place
 constexpr int MW = IW - 1;        // waves on the final-layer product (wave 0 inverts the spline meanwhile)
 constexpr int NI = (IT / SS + MW - 1) / MW;   // super-steps per wave at most
-constexpr int NRED = (IR * 32 + MW * 64 - 1) / (MW * 64);   // parameter sums per thread of waves 1..7
 
 constexpr int F_RELU_IN = 1, F_RESIDUAL = 2, F_RELU_OUT = 4;
+
+// First super-step of feature f in the triangular final-layer pack: sum over g < f of ceil(g / 8)
+__host__ __device__ inline int first_superstep(int f) {
+    if (f <= 1) return 0;
+    const int m = f - 1, q = m / SS;
+    return (q + 1) * (m - (SS / 2) * q);
+}
 
 struct InvArgs {
     const float* z;
@@ -60,7 +67,6 @@ struct InvArgs {
     const float* bf;              // [H+1][32] final-layer bias of features 0..H, columns >= P zero
     const float* wl;              // [H+1][2][32] wl[f][0][c] = W[f*P+c][f-1], wl[f][1][c] = W[f*P+c][f-2]
     const float* dg;              // [H][16] unit j: [s] = step s's weight on unit j of the step before, [8+s] = on unit j-1
-    const int32_t* off;           // [H+2] first super-step of each feature in wf
     const float4* wf;             // [super-step][lane]: lane (kh, col) holds W[f*P+col][8S+4kh .. +3], units >= f-2 zeroed
     int flags[MAXSTEP];
     int64_t B;
@@ -73,48 +79,50 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* hlT = smem;                              // [HS][IR] final hidden state, unit-major
     float* part = hlT + g.HS * IR;                  // [2][MW][IR][32] per-wave partial parameter tiles, by feature parity
-    float* prmb = part + 2 * MW * IR * 32;          // [2][32][PSTR] bulk parameters, by feature parity
-    float* prm = prmb + 2 * 32 * PSTR;              // [32][PSTR] wave 0's completed parameters
+    float* prmb = part + 2 * MW * IR * 32;          // [2][IR][32] bulk parameters, by feature parity
+    float* prm = prmb + 2 * IR * 32;              // [32][PSTR] wave 0's completed parameters
     float* bc = prm + 32 * PSTR;                    // [2][MAXSTEP][IR] activations of the unit just finished, by parity
     float* sh = bc + 2 * MAXSTEP * IR;              // [2][MAXSTEP][IR] exported running sums of the next unit, by parity
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar branches on the wave's role)
     const int64_t m0 = (int64_t)blockIdx.x * IR;
     const int H = g.H, HS = g.HS;
     const bool unit = tid < H;
     const int kcol = unit ? tid : 0;
 
-    f32x2 acc[NSTEP][IR / 2];
+    float acc[NSTEP][IR];
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
         const float b = unit ? g.bias[s][kcol] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < IR / 2; ++r) acc[s][r] = (f32x2){b, b};
+        for (int r = 0; r < IR; ++r) acc[s][r] = b;
     }
     for (int e = tid; e < HS * IR; e += IT) hlT[e] = 0.0f;
     for (int e = tid; e < 2 * MW * IR * 32; e += IT) part[e] = 0.0f;
-    for (int e = tid; e < IR * 32; e += IT) prmb[(e & 31) * PSTR + (e >> 5)] = g.bf[e & 31];   // feature 0: bias alone
+    for (int e = tid; e < IR * 32; e += IT) prmb[e] = g.bf[e & 31];       // feature 0: bias alone
     if (tid == 0) {                                 // unit 0's running sums: nothing precedes it
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
-            for (int r = 0; r < IR / 2; ++r) reinterpret_cast<f32x2*>(sh + s * IR)[r] = acc[s][r];
+            for (int r = 0; r < IR; ++r) sh[s * IR + r] = acc[s][r];
     }
 
     // Per-role state in one register array (wave 0 never runs the bulk product, the others never invert splines):
     //   wave 0:     rs[0..NSTEP) = activations of the unit finished last round, rs[5] = next unit's weight record,
     //               rs[6] = final hidden value of unit j-1, rs[7] = next input z, rs[8] = running logdet sum,
     //               rs[9] = next feature's two newest-unit weight rows (lane = [row][column])
-    //   waves 1..7: rs[8] = next bias
-    float rs[10];
+    //   waves 1..7: rs[0..4) = next feature's bias, four columns (waves 1..4), rs[4..12) = next round's first two B operands
+    float rs[12];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) rs[i] = 0.0f;
+    for (int i = 0; i < 12; ++i) rs[i] = 0.0f;
     if (wave == 0) {
         rs[7] = tid < IR ? g.z[((m0 + tid < g.B) ? m0 + tid : g.B - 1) * g.ldz] : 0.0f;
         rs[5] = g.dg[tid & 15];
         rs[9] = g.wl[lane];
-    } else {
-        rs[8] = g.bf[32 + (tid & 31)];      // parameter sums (waves 1..7): column tid & 31 of NRED samples
+    } else if (wave <= 4) {                 // parameter sums: columns 4 (tid & 7) .. + 3 of one sample
+        const float4 nb = *reinterpret_cast<const float4*>(g.bf + 32 + ((tid * 4) & 31));
+        rs[0] = nb.x; rs[1] = nb.y; rs[2] = nb.z; rs[3] = nb.w;
     }
 
     float wcur[NSTEP];
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
         // register pressure, and were spilled to scratch - with a scratch reload in front of every MFMA group.
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, arow = tid & 31, kh = (tid >> 5) & 1, rc = tid & 31;
+        const int lane = tid & 63, arow = tid & 31, kh = (tid >> 5) & 1;
         const int kcol = tid < H ? tid : 0;
         if (wave == 0) {
             // ---- the critical path: feature j and hidden unit j
@@ -147,10 +155,10 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
             // 32 x 32 x 2 MFMA on the bulk tile (lanes 0..31 hold h(j-1) of their sample, lanes 32..63 fetch h(j-2))
             {
                 const float a = lane < IR ? rs[6] : (j >= 2 ? hlT[(j - 2) * IR + arow] : 0.0f);
-                const float* pb = prmb + (par * 32 + arow) * PSTR + 4 * kh;
+                const float* pb = prmb + par * IR * 32 + 4 * kh * 32 + arow;
                 f32x16 c;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) c[i] = pb[(i & 3) + 8 * (i >> 2)];
+                for (int i = 0; i < 16; ++i) c[i] = pb[((i & 3) + 8 * (i >> 2)) * 32];
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rs[9], c, 0, 0, 0);
                 float* po = prm + arow * PSTR + 4 * kh;
 #pragma unroll
@@ -211,25 +219,112 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 
         // ---- waves 1..7: the B operands of this round's product first, the update below covers their latency
         const int NS = (j + SS - 1) / SS;
-        const int64_t fo = g.off[j + 2 <= H ? j + 2 : H];
+        const int64_t fo = first_superstep(j + 2 <= H ? j + 2 : H);
         float4 bq[NQ];
         if (wave > 0 && j + 2 <= H) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
-                const int S = wave - 1 + MW * i;
+                const int S = wave - 1 + MW * (NP + i);
                 if (S < NS) bq[i] = g.wf[(fo + S) * 64 + lane];
             }
         }
 
+        STAMP(7)
+        // Waves w and w + 4 share a SIMD.  Waves 1..3 own the low units, which are finished early, so they take
+        // the matrix product first and their update (if any) second; waves 4..7 the other way round: one wave's
+        // MFMAs run under the other's VALU work instead of both queueing on the same pipe.
+        const bool product_first = wave >= 1 && wave <= 3;
+        auto product = [&]() {
+        if (wave > 0) {
+        // ---- feature j+2 over the hidden units 0..j-1 (units j, j+1 join as rank-1 terms in wave 0)
+        if (j + 2 <= H) {
+            f32x16 d;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int S = wave - 1 + MW * i;
+                if (S < NS) {
+                    const float* ap = hlT + (SS * S + 4 * kh) * IR + arow;
+                    const float a0 = ap[0], a1 = ap[IR], a2 = ap[2 * IR], a3 = ap[3 * IR];
+                    // the first NP super-steps' operands came in a round ahead (the latency of these loads is 1500+
+                    // cycles: the weights live in MALL / HBM), the next NQ at the top of this round, the rest follow
+                    // in place NQ super-steps behind their slot's previous user
+                    float4 b;
+                    if (i < NP) {
+                        b = make_float4(rs[4 + 4 * (i % NP)], rs[5 + 4 * (i % NP)], rs[6 + 4 * (i % NP)], rs[7 + 4 * (i % NP)]);
+                    } else {
+                        b = bq[(i - NP) % NQ];
+                        if (i + NQ < NI && S + NQ * MW < NS) bq[(i - NP) % NQ] = g.wf[(fo + S + NQ * MW) * 64 + lane];
+                    }
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.z, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b.w, d, 0, 0, 0);
+                }
+            }
+            float* pt = part + (par * MW + wave - 1) * IR * 32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
+                pt[r * 32 + arow] = d[i];
+            }
+            if (j + 3 <= H) {                           // next round: feature j+3 over units 0..j
+                const int NS1 = (j + SS) / SS;
+                const int64_t o = first_superstep(j + 3);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const int S = wave - 1 + MW * i;
+                    if (S < NS1) {
+                        const float4 n = g.wf[(o + S) * 64 + lane];
+                        rs[4 + 4 * i] = n.x; rs[5 + 4 * i] = n.y; rs[6 + 4 * i] = n.z; rs[7 + 4 * i] = n.w;
+                    }
+                }
+            }
+        }
+        }
+    STAMP(4)
+        };
+        auto sums = [&]() {
+            // ---- bulk parameters of feature j+1: bias + last round's partial tiles, fixed order; waves 1..4,
+            //      one sample and four columns per thread
+            {
+                const int e = (tid - 64) * 4;                       // [sample][column] element
+                const float* pp = part + (par ^ 1) * MW * IR * 32 + e;
+                float4 s = make_float4(rs[0], rs[1], rs[2], rs[3]);
+#pragma unroll
+                for (int w = 0; w < MW; ++w) {
+                    const float4 t = *reinterpret_cast<const float4*>(pp + w * IR * 32);
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
+                *reinterpret_cast<float4*>(prmb + (par ^ 1) * IR * 32 + e) = s;
+                const float4 nb = *reinterpret_cast<const float4*>(g.bf + (j + 2 <= H ? j + 2 : H) * 32 + (e & 31));
+                rs[0] = nb.x; rs[1] = nb.y; rs[2] = nb.z; rs[3] = nb.w;
+            }
+        };
+        if (product_first) {
+            sums();                                     // (LDS only: covers the latency of the B operands)
+            product();
+        }
         // ---- everyone, one round behind: unit j-1's activations into the running sums of the units after it
         if (j > 0 && wave * 64 + 63 > j) {              // units <= j are finished or being finished by wave 0
-            const float* b = bc + ((par ^ 1) * MAXSTEP) * IR;
+            // every thread needs all 32 activations of a step; as LDS broadcast reads that was 40 ds_read_b128 per
+            // wave and round, 2500 cycles of LDS pipe per round for the workgroup.  Instead each 16-lane row loads
+            // the 32 values once (two registers per lane) and the FMAs take them through DPP row_share.
+            const float* b = bc + ((par ^ 1) * MAXSTEP) * IR + (tid & 15);
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
-                const f32x2 w2 = (f32x2){wcur[s], wcur[s]};
-                const f32x2* v2 = reinterpret_cast<const f32x2*>(b + s * IR);
-#pragma unroll
-                for (int r = 0; r < IR / 2; ++r) acc[s][r] = __builtin_elementwise_fma(w2, v2[r], acc[s][r]);
+                const float lo = b[s * IR], hi = b[s * IR + 16];
+                const float w = wcur[s];
+                // acc += w * (lane r_ of this lane's row of 16): the DPP operand folded into the FMA (hipcc leaves a
+                // separate v_mov_b32_dpp per product otherwise)
+#define NF_ROW_FMA(r_) \
+                asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #r_ " row_mask:0xf bank_mask:0xf" : "+v"(acc[s][r_]) : "v"(lo), "v"(w)); \
+                asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #r_ " row_mask:0xf bank_mask:0xf" : "+v"(acc[s][16 + r_]) : "v"(hi), "v"(w));
+                asm volatile("s_nop 1" ::: "memory");
+                NF_ROW_FMA(0) NF_ROW_FMA(1) NF_ROW_FMA(2) NF_ROW_FMA(3) NF_ROW_FMA(4) NF_ROW_FMA(5) NF_ROW_FMA(6) NF_ROW_FMA(7)
+                NF_ROW_FMA(8) NF_ROW_FMA(9) NF_ROW_FMA(10) NF_ROW_FMA(11) NF_ROW_FMA(12) NF_ROW_FMA(13) NF_ROW_FMA(14) NF_ROW_FMA(15)
+#undef NF_ROW_FMA
             }
         }
         {
@@ -242,61 +337,23 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
-                for (int r = 0; r < IR / 2; ++r) reinterpret_cast<f32x2*>(sh + ((par ^ 1) * MAXSTEP + s) * IR)[r] = acc[s][r];
+                for (int r = 0; r < IR; r += 4)
+                    *reinterpret_cast<float4*>(sh + ((par ^ 1) * MAXSTEP + s) * IR + r) =
+                        make_float4(acc[s][r], acc[s][r + 1], acc[s][r + 2], acc[s][r + 3]);
         }
-        STAMP(3)
-        if (wave > 0) {
-            // ---- feature j+2 over the hidden units 0..j-1 (units j, j+1 join as rank-1 terms in wave 0)
-            if (j + 2 <= H) {
-                f32x16 d;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) d[i] = 0.0f;
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int S = wave - 1 + MW * i;
-                    if (S < NS) {
-                        const float* ap = hlT + (SS * S + 4 * kh) * IR + arow;
-                        const float a0 = ap[0], a1 = ap[IR], a2 = ap[2 * IR], a3 = ap[3 * IR];
-                        const float4 b = bq[i % NQ];
-                        // the slot's next user (NQ super-steps of this wave later) is loaded behind these MFMAs
-                        if (i + NQ < NI && S + NQ * MW < NS) bq[i % NQ] = g.wf[(fo + S + NQ * MW) * 64 + lane];
-                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.z, d, 0, 0, 0);
-                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b.w, d, 0, 0, 0);
-                    }
-                }
-                float* pt = part + (par * MW + wave - 1) * IR * 32;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
-                    pt[r * 32 + arow] = d[i];
-                }
-            }
-            STAMP(4)
-            // ---- bulk parameters of feature j+1: bias + last round's partial tiles, fixed order
-            const float* pp = part + (par ^ 1) * MW * IR * 32;
-            float* po = prmb + (par ^ 1) * 32 * PSTR;
-#pragma unroll
-            for (int h = 0; h < NRED; ++h) {
-                const int r = ((tid - 64) >> 5) + (MW * 2) * h;
-                if (r < IR) {
-                    float s = rs[8];
-#pragma unroll
-                    for (int w = 0; w < MW; ++w) s += pp[(w * IR + r) * 32 + rc];
-                    po[rc * PSTR + r] = s;
-                }
-            }
-            rs[8] = g.bf[(j + 2 <= H ? j + 2 : H) * 32 + rc];
-        }
+    STAMP(3)
+        if (wave >= 4) product();
+        if (wave == 4) sums();
         STAMP(5)
-        __syncthreads();
+        // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait out every global load issued a round
+        // ahead on purpose (next weights, B operands, z) - 1500 cycles per round when measured
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         STAMP(6)
     }
 #ifdef NF_INV_STAMP
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
-        printf("wave %d: params %u | eval %u | unit %u | update %u | mfma %u | sums %u | barrier %u (cycles per round)\n", wave,
-               stamps[wave * 8] / H, stamps[wave * 8 + 1] / H, stamps[wave * 8 + 2] / H, stamps[wave * 8 + 3] / H,
+        printf("wave %d: params %u | eval %u | unit/export %u | loads %u | update %u | mfma %u | sums %u | barrier %u (cycles per round)\n", wave,
+               stamps[wave * 8] / H, stamps[wave * 8 + 1] / H, stamps[wave * 8 + 2] / H, stamps[wave * 8 + 7] / H, stamps[wave * 8 + 3] / H,
                stamps[wave * 8 + 4] / H, stamps[wave * 8 + 5] / H, stamps[wave * 8 + 6] / H);
 #endif
 
@@ -309,12 +366,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 }
 
 inline int hs_of(int H) { return (H + 63) / 64 * 64; }
-inline int64_t total_supersteps(int H) {
-    int64_t t = 0;
-    for (int f = 0; f <= H; ++f) t += (f + SS - 1) / SS;
-    return t;
-}
-inline int off_len(int H) { return (H + 2 + 3) / 4 * 4; }
+inline int64_t total_supersteps(int H) { return first_superstep(H + 1); }
 
 template <int NSTEP>
 int launch_steps(const InvArgs& g, int K, unsigned grid, size_t lds, hipStream_t s) {
@@ -339,7 +391,7 @@ extern "C" int nf_made_rqs_inverse_rows_supported(int features, int hidden, int 
 extern "C" size_t nf_made_inverse_blob_floats(int hidden, int n_steps) {
     if (hidden <= 0 || hidden > IT || n_steps < 1 || n_steps > MAXSTEP) return 0;
     const size_t H = hidden, HS = hs_of(hidden);
-    return n_steps * (H + 1) * HS + 3 * (H + 1) * 32 + H * 16 + off_len(hidden) + (size_t)total_supersteps(hidden) * 256;
+    return n_steps * (H + 1) * HS + 3 * (H + 1) * 32 + H * 16 + (size_t)total_supersteps(hidden) * 256;
 }
 
 extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags,
@@ -373,14 +425,13 @@ extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_ste
     g.bf = p; p += (size_t)(H + 1) * 32;
     g.wl = p; p += (size_t)(H + 1) * 64;
     g.dg = p; p += (size_t)H * 16;
-    g.off = reinterpret_cast<const int32_t*>(p); p += off_len(H);
     g.wf = reinterpret_cast<const float4*>(p);
     g.z = z; g.ldz = z_row_stride; g.x = x; g.ldx = x_row_stride; g.hid = hidden_out; g.ldh = h_row_stride;
     g.partial = workspace; g.B = B; g.H = H; g.HS = HS;
     g.full_tiles = (H + 1) / g.fpt;
     const int64_t grid = (B + IR - 1) / IR;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    const size_t lds = sizeof(float) * ((size_t)HS * IR + 2 * MW * IR * 32 + 3 * 32 * PSTR + 4 * MAXSTEP * IR + IW * 8);
+    const size_t lds = sizeof(float) * ((size_t)HS * IR + 2 * MW * IR * 32 + 2 * IR * 32 + 32 * PSTR + 4 * MAXSTEP * IR + IW * 8);
     hipStream_t st = (hipStream_t)stream;
     switch (n_steps) {
         case 2: return launch_steps<2>(g, K, (unsigned)grid, lds, st);
