@@ -264,6 +264,15 @@ int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const i
                              int K, int tails, double tail_bound, double min_bin_width, double min_bin_height,
                              double min_derivative, void* stream);
 
+/* The same for MaskedAffineAutoregressiveTransform (transforms.py:511-566): blob with 2 parameters per feature
+ * (unconstrained scale, shift interleaved, P = 2 in the layout above).  x[b, 0..hidden] and the final hidden state
+ * are written; the caller finishes with the final layer on hidden_out (nf_masked_linear_fwd) and one nf_affine_fwd
+ * (inverse = 1) over all features, which also gives logabsdet. */
+int nf_made_affine_inverse_rows_supported(int features, int hidden, int n_steps);
+int nf_made_affine_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags, const float* z,
+                                int64_t z_row_stride, float* x, int64_t x_row_stride, float* hidden_out,
+                                int64_t h_row_stride, int64_t B, int features, void* stream);
+
 /* ---- affine transform (replaces transforms.py:328-347 coupling, :540-566 autoregressive) -------- */
 
 /* scale = sigmoid(u + 2) + 1e-3; forward y = scale*x + shift, inverse y = (x - shift)/scale;

@@ -100,6 +100,10 @@ _SIGNATURES = {
                                             _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_size_t,
                                             _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double,
                                             _c.c_double, _c.c_double, _c.c_void_p]),
+    'nf_made_affine_inverse_rows_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
+    'nf_made_affine_inverse_rows': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                               _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
+                                               _c.c_void_p]),
     'nf_made_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -464,10 +468,14 @@ class PackedInverse:
     __slots__ = ('hidden', 'features', 'P', 'K', 'tails', 'n_steps', 'flags', 'blob')
 
     def __init__(self, steps, final_weight, final_mask, final_bias, features, num_bins, tails):
+        """num_bins None: the affine transform (2 parameters per feature)."""
         lib = load()
         H = int(final_weight.shape[1])
         t = 1 if tails == 'linear' else 0
-        P = 3 * num_bins - 1 if t else 3 * num_bins + 1
+        if num_bins is None:
+            P, num_bins = 2, 0
+        else:
+            P = 3 * num_bins - 1 if t else 3 * num_bins + 1
         HS = (H + 63) // 64 * 64
         dev = final_weight.device
         parts, flags = [], []
@@ -524,6 +532,31 @@ def made_rqs_inverse_rows_supported(features, hidden, n_steps, num_bins, tails):
     return (tails in (None, 'linear')
             and load().nf_made_rqs_inverse_rows_supported(int(features), int(hidden), int(n_steps), int(num_bins),
                                                           1 if tails == 'linear' else 0) == 1)
+
+
+def made_affine_inverse_rows_supported(features, hidden, n_steps):
+    return load().nf_made_affine_inverse_rows_supported(int(features), int(hidden), int(n_steps)) == 1
+
+
+def made_affine_inverse_rows(pi, z, out, hidden):
+    """Features 0..H of the affine autoregressive inverse and the final hidden state (nf_made_affine_inverse_rows)."""
+    lib = load()
+    _dev(z, 'inputs')
+    _dev(out, 'outputs')
+    _dev(hidden, 'hidden')
+    B = z.shape[0]
+    zp, zs = _rows(z, 'inputs')
+    xp, xs = _rows(out, 'outputs')
+    hp, hs = _rows(hidden, 'hidden')
+    if pi.P != 2 or z.shape[1] != pi.features or out.shape != z.shape or hidden.shape != (B, pi.hidden):
+        raise ValueError('Expected an affine pack, inputs / outputs [B,%d] and hidden [B,%d]' % (pi.features, pi.hidden))
+
+    def launch():
+        return lib.nf_made_affine_inverse_rows(pi.blob.data_ptr(), pi.hidden, pi.n_steps, pi.flags, zp, zs, xp, xs, hp,
+                                               hs, B, pi.features, _stream())
+    with torch.cuda.device(z.device):
+        code = launch() if _timer is None else _timer.record(('made_affine_inverse_rows', pi.hidden, pi.features, B), launch)
+        _check(code, 'nf_made_affine_inverse_rows')
 
 
 def made_rqs_inverse_rows(pi, z, out, hidden, workspace, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,

@@ -46,6 +46,7 @@ constexpr int MW = IW - 1;        // waves on the final-layer product (wave 0 in
 constexpr int NI = (IT / SS + MW - 1) / MW;   // super-steps per wave at most
 
 constexpr int F_RELU_IN = 1, F_RESIDUAL = 2, F_RELU_OUT = 4;
+constexpr int KT_AFFINE = -1;     // elementwise transform: affine (2 parameters per feature) instead of the spline
 
 // First super-step of feature f in the triangular final-layer pack: sum over g < f of ceil(g / 8)
 __host__ __device__ inline int first_superstep(int f) {
@@ -174,8 +175,18 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 #ifdef NF_NOEVAL
                 y = prm[tid] + rs[7]; ld = prm[tid + PSTR]; bin = 0;
 #else
-                typedef const __attribute__((address_space(3))) float* lds_ptr;
-                rqs_eval<KT, true, PSTR, false, false, lds_ptr>((lds_ptr)(prm + tid), rs[7], g.c, y, ld, bin);
+                if constexpr (KT == KT_AFFINE) {
+                    // scale = sigmoid(u + 2) + 1e-3, x = (z - shift) / scale (models/transforms.py:540-566; same
+                    // arithmetic as affine_kernel in nf_spline.hip)
+                    const float us = prm[tid], shift = prm[PSTR + tid];
+                    const float scale = 1.0f / (1.0f + expf(-(us + 2.0f))) + 1e-3f;
+                    y = (rs[7] - shift) / scale;
+                    ld = -logf(scale);
+                    bin = 0;
+                } else {
+                    typedef const __attribute__((address_space(3))) float* lds_ptr;
+                    rqs_eval<KT, true, PSTR, false, false, lds_ptr>((lds_ptr)(prm + tid), rs[7], g.c, y, ld, bin);
+                }
 #endif
                 if (row_ok) g.x[row * g.ldx + j] = y;
                 rs[8] += ld;
@@ -376,6 +387,7 @@ int launch_steps(const InvArgs& g, int K, unsigned grid, size_t lds, hipStream_t
         hipLaunchKernelGGL(kern, dim3(grid), dim3(IT), lds, s, g);
         return nf_launch_status();
     };
+    if (K == KT_AFFINE) return go(made_rqs_inverse_kernel<NSTEP, KT_AFFINE>);
     return K == 8 ? go(made_rqs_inverse_kernel<NSTEP, 8>) : go(made_rqs_inverse_kernel<NSTEP, 0>);
 }
 
@@ -394,23 +406,17 @@ extern "C" size_t nf_made_inverse_blob_floats(int hidden, int n_steps) {
     return n_steps * (H + 1) * HS + 3 * (H + 1) * 32 + H * 16 + (size_t)total_supersteps(hidden) * 256;
 }
 
-extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags,
-                                        const float* z, int64_t z_row_stride, float* x, int64_t x_row_stride,
-                                        float* hidden_out, int64_t h_row_stride, float* workspace,
-                                        size_t workspace_bytes, int64_t B, int features, int K, int tails,
-                                        double tail_bound, double min_bin_width, double min_bin_height,
-                                        double min_derivative, void* stream) {
-    if (B < 0 || !nf_made_rqs_inverse_rows_supported(features, hidden, n_steps, K, tails)) return NF_ERR_SHAPE;
-    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+static int inverse_rows_impl(const float* blob, int hidden, int n_steps, const int* step_flags, const float* z,
+                             int64_t z_row_stride, float* x, int64_t x_row_stride, float* hidden_out,
+                             int64_t h_row_stride, float* workspace, int64_t B, int features, int K, const RqsConst& c,
+                             void* stream) {
     if (B == 0) return NF_OK;
-    if (!blob || !step_flags || !z || !x || !hidden_out || !workspace) return NF_ERR_NULL;
+    if (!blob || !step_flags || !z || !x || !hidden_out) return NF_ERR_NULL;
     if (z_row_stride < features || x_row_stride < features || h_row_stride < hidden || ((uintptr_t)blob & 15) != 0)
         return NF_ERR_LAYOUT;
     InvArgs g;
-    g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
+    g.c = c;
     g.fpt = 256 / g.c.P;
-    const int all_tiles = (features + g.fpt - 1) / g.fpt;
-    if (workspace_bytes < sizeof(float) * (size_t)all_tiles * (size_t)B) return NF_ERR_SCRATCH;
     const int H = hidden, HS = hs_of(hidden);
     const float* p = blob;
     for (int s = 0; s < MAXSTEP; ++s) {
@@ -428,7 +434,7 @@ extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_ste
     g.wf = reinterpret_cast<const float4*>(p);
     g.z = z; g.ldz = z_row_stride; g.x = x; g.ldx = x_row_stride; g.hid = hidden_out; g.ldh = h_row_stride;
     g.partial = workspace; g.B = B; g.H = H; g.HS = HS;
-    g.full_tiles = (H + 1) / g.fpt;
+    g.full_tiles = workspace ? (H + 1) / g.fpt : 0;
     const int64_t grid = (B + IR - 1) / IR;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
     const size_t lds = sizeof(float) * ((size_t)HS * IR + 2 * MW * IR * 32 + 2 * IR * 32 + 32 * PSTR + 4 * MAXSTEP * IR + IW * 8);
@@ -440,4 +446,36 @@ extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_ste
         case 5: return launch_steps<5>(g, K, (unsigned)grid, lds, st);
     }
     return NF_ERR_SHAPE;
+}
+
+extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags,
+                                        const float* z, int64_t z_row_stride, float* x, int64_t x_row_stride,
+                                        float* hidden_out, int64_t h_row_stride, float* workspace,
+                                        size_t workspace_bytes, int64_t B, int features, int K, int tails,
+                                        double tail_bound, double min_bin_width, double min_bin_height,
+                                        double min_derivative, void* stream) {
+    if (B < 0 || !nf_made_rqs_inverse_rows_supported(features, hidden, n_steps, K, tails)) return NF_ERR_SHAPE;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+    if (B > 0 && !workspace) return NF_ERR_NULL;
+    const RqsConst c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
+    const int fpt = 256 / c.P, all_tiles = (features + fpt - 1) / fpt;
+    if (workspace_bytes < sizeof(float) * (size_t)all_tiles * (size_t)B) return NF_ERR_SCRATCH;
+    return inverse_rows_impl(blob, hidden, n_steps, step_flags, z, z_row_stride, x, x_row_stride, hidden_out,
+                             h_row_stride, workspace, B, features, K, c, stream);
+}
+
+extern "C" int nf_made_affine_inverse_rows_supported(int features, int hidden, int n_steps) {
+    return features >= 2 && hidden >= 1 && hidden <= IT && hidden <= features - 1 && hidden % 8 == 0 && n_steps >= 2 &&
+                   n_steps <= MAXSTEP ? 1 : 0;
+}
+
+extern "C" int nf_made_affine_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags,
+                                           const float* z, int64_t z_row_stride, float* x, int64_t x_row_stride,
+                                           float* hidden_out, int64_t h_row_stride, int64_t B, int features,
+                                           void* stream) {
+    if (B < 0 || !nf_made_affine_inverse_rows_supported(features, hidden, n_steps)) return NF_ERR_SHAPE;
+    RqsConst c = nf_make_rqs_const(1, 1, 1.0, 0.0, 0.0, 0.0, 1.0);
+    c.P = 2;                                    // (scale, shift) interleaved per feature
+    return inverse_rows_impl(blob, hidden, n_steps, step_flags, z, z_row_stride, x, x_row_stride, hidden_out,
+                             h_row_stride, nullptr, B, features, KT_AFFINE, c, stream);
 }

@@ -345,7 +345,8 @@ class MADE(nn.Module):
         return bufs[last]
 
     def inverse_rows_pack(self, num_bins, tails):
-        """Parameter blob for the row-resident inverse kernel (nf_made_rqs_inverse_rows), or None when this
+        """Parameter blob for the row-resident inverse kernel (nf_made_rqs_inverse_rows; num_bins None: the affine
+        variant nf_made_affine_inverse_rows), or None when this
         network is outside its scope: hidden units must be in degree order in every layer (the non-random masks
         with hidden_features <= features - 1), no BatchNorm, the step structure of hidden_program()."""
         steps, _ = self.hidden_program()
@@ -357,7 +358,8 @@ class MADE(nn.Module):
             return cached[1]
         D, H = self.initial_layer.in_features, self.final_layer.in_features
         pack = None
-        ok = _lib.made_rqs_inverse_rows_supported(D, H, len(steps), num_bins, tails)
+        ok = (_lib.made_affine_inverse_rows_supported(D, H, len(steps)) if num_bins is None
+              else _lib.made_rqs_inverse_rows_supported(D, H, len(steps), num_bins, tails))
         flags = []
         want = torch.arange(1, H + 1)
         for i, (layer, src, dst, res, relu_in, relu_out, bn) in enumerate(steps):

@@ -156,6 +156,30 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
     def _elementwise(self, inputs, params, outputs, logabsdet, inverse):
         _lib.affine(inputs, params, _lib.NF_AFFINE_INTERLEAVED, inverse=inverse, out=outputs, logabsdet=logabsdet)
 
+    def inverse(self, inputs, context=None):
+        """Same result as the reference's D full passes (transforms.py:493-500).  With hidden units in degree
+        order one launch carries 32 samples per workgroup through features 0..H (nf_inverse.hip, see the spline
+        transform below); x = (z - shift) / scale is elementwise in z once the parameters are known, so the final
+        hidden state that launch leaves behind gives every feature and logabsdet in one GEMM + one affine pass."""
+        net = self.autoregressive_net
+        if self._recording(inputs):
+            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
+        pi = net.inverse_rows_pack(None, None) if ROW_RESIDENT_INVERSE and context is None else None
+        if pi is None:
+            return super().inverse(inputs, context)
+        D = net.initial_layer.in_features
+        _check_2d(inputs, D)
+        made_module._require_inference(net.final_layer)
+        B, H = inputs.shape[0], net.final_layer.in_features
+        outputs = torch.zeros_like(inputs)
+        logabsdet = torch.zeros(B, dtype=inputs.dtype, device=inputs.device)
+        for s in range(0, B, CHUNK_ROWS):
+            e = min(B, s + CHUNK_ROWS)
+            hidden = torch.empty((e - s, H), dtype=inputs.dtype, device=inputs.device)
+            _lib.made_affine_inverse_rows(pi, inputs[s:e], outputs[s:e], hidden)
+            self._elementwise(inputs[s:e], net.final_layer.fused(hidden), outputs[s:e], logabsdet[s:e], inverse=True)
+        return outputs, logabsdet
+
 
 class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTransform):
     """Rational-quadratic spline MAF layer (reference transforms.py:771-866).  As in the reference the
