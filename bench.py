@@ -231,6 +231,21 @@ def main():
                                             'max_rel_diff_vs_headline_log_prob':
                                                 ((lpm - logp).abs() / logp.abs().clamp_min(1.0)).max().item()}
             nf.set_matmul_dtype(args.dtype)
+            # the other direction of the same flow: sample = transform.inverse(z) (reference distributions.py:192-193,
+            # transforms.py:493-500: D conditioner passes per layer; here one row-resident launch per layer)
+            ns = min(B, 65536)
+            zs = torch.randn(ns, D, device=dev, generator=torch.Generator(device=dev).manual_seed(99))
+            with torch.no_grad():
+                xs, lds = flow.forward(zs)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                xs, lds = flow.forward(zs)
+                torch.cuda.synchronize()
+                dts = time.perf_counter() - t1
+                zb, ldb = flow.reverse(xs)
+            out['inverse_sampling'] = {'value': ns / dts, 'unit': 'samples/s (this rank)', 'batch': ns,
+                                       'roundtrip_max_abs_err': (zb - zs).abs().max().item(),
+                                       'logdet_cancel_max_abs': (lds + ldb).abs().max().item()}
         f32_tf, bf16_tf, copy_gbs = nf._lib.measure_device_peaks()
         out['measured_device_peaks'] = {'mfma_f32_tflops': f32_tf, 'mfma_bf16_tflops': bf16_tf, 'copy_gbs': copy_gbs,
                                         'note': 'back-to-back MFMA issue loop / 1 GiB float4 copy on this device; the '

@@ -382,6 +382,34 @@ def test_affine_ar_row_resident_inverse(nf, shape):
     assert (back - z).abs().max().item() < 1e-3 and (ld_f + fast_ld).abs().max().item() < 5e-3
 
 
+def test_rq_ar_row_resident_inverse_strides_and_chunks(nf):
+    """Row views with a row stride wider than D, an empty batch, and a batch split over several launch groups give
+    the rows the plain call gives."""
+    from normalizing_flows_amd import transforms as tr
+    torch.manual_seed(13)
+    D, H, K = 72, 40, 8
+    t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, num_bins=K, tails='linear',
+                                                                   tail_bound=3.).cuda().eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+        wide = torch.randn(150, D + 9, device='cuda') * 1.5
+        z = wide[:, 3:3 + D]
+        assert not z.is_contiguous()
+        x0, ld0 = t.inverse(z.contiguous())
+        x1, ld1 = t.inverse(z)
+        old = tr.CHUNK_ROWS
+        tr.CHUNK_ROWS = 64
+        try:
+            x2, ld2 = t.inverse(z)
+        finally:
+            tr.CHUNK_ROWS = old
+        xe, lde = t.inverse(z[:0])
+    assert torch.equal(x1, x0) and torch.equal(ld1, ld0)
+    assert torch.equal(x2, x0) and torch.equal(ld2, ld0)
+    assert xe.shape == (0, D) and lde.shape == (0,)
+
+
 def test_rq_ar_row_resident_inverse_scope(nf):
     """Networks the row-resident kernel does not cover keep the windowed path: wrap-around degrees, BatchNorm."""
     mk = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform
