@@ -32,6 +32,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int IR = 32;            // samples per workgroup
@@ -92,21 +93,24 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
     const bool unit = tid < H;
     const int kcol = unit ? tid : 0;
 
-    float acc[NSTEP][IR];
+    // Running sums of the hidden units, in the accumulator layout of v_mfma_f32_32x32x1_2b_f32: wave w holds units
+    // 64w .. 64w+63 as two 32 x 32 (unit x sample) blocks per step; register r of lane l is
+    //   unit 64w + 32 (r >> 4) + (r & 3) + 8 ((r & 15) >> 2) + 4 (l >> 5),  sample l & 31.
+    f32x32 acc[NSTEP];
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-        const float b = unit ? g.bias[s][kcol] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < IR; ++r) acc[s][r] = b;
+        for (int r = 0; r < 32; ++r) {
+            const int u = 64 * wave + 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * (lane >> 5);
+            acc[s][r] = u < H ? g.bias[s][u] : 0.0f;
+        }
     }
     for (int e = tid; e < HS * IR; e += IT) hlT[e] = 0.0f;
     for (int e = tid; e < 2 * MW * IR * 32; e += IT) part[e] = 0.0f;
     for (int e = tid; e < IR * 32; e += IT) prmb[e] = g.bf[e & 31];       // feature 0: bias alone
-    if (tid == 0) {                                 // unit 0's running sums: nothing precedes it
+    if (tid < IR) {                                 // unit 0's running sums: nothing precedes it
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s)
-#pragma unroll
-            for (int r = 0; r < IR; ++r) sh[s * IR + r] = acc[s][r];
+        for (int s = 0; s < NSTEP; ++s) sh[s * IR + tid] = g.bias[s][0];
     }
 
     // Per-role state in one register array (wave 0 never runs the bulk product, the others never invert splines):
@@ -319,24 +323,13 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
         }
         // ---- everyone, one round behind: unit j-1's activations into the running sums of the units after it
         if (j > 0 && wave * 64 + 63 > j) {              // units <= j are finished or being finished by wave 0
-            // every thread needs all 32 activations of a step; as LDS broadcast reads that was 40 ds_read_b128 per
-            // wave and round, 2500 cycles of LDS pipe per round for the workgroup.  Instead each 16-lane row loads
-            // the 32 values once (two registers per lane) and the FMAs take them through DPP row_share.
-            const float* b = bc + ((par ^ 1) * MAXSTEP) * IR + (tid & 15);
+            // one rank-1 update per hidden step: (this wave's 64 weights on unit j-1) x (its 32 activations), a
+            // 2-block 32 x 32 x 1 MFMA each - the matrix pipe has room beside the bulk product, the VALU did not
+            // (160 DPP FMAs per wave and round were 2500 cycles with two waves per SIMD)
+            const float* b = bc + ((par ^ 1) * MAXSTEP) * IR + (tid & 31);
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) {
-                const float lo = b[s * IR], hi = b[s * IR + 16];
-                const float w = wcur[s];
-                // acc += w * (lane r_ of this lane's row of 16): the DPP operand folded into the FMA (hipcc leaves a
-                // separate v_mov_b32_dpp per product otherwise)
-#define NF_ROW_FMA(r_) \
-                asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #r_ " row_mask:0xf bank_mask:0xf" : "+v"(acc[s][r_]) : "v"(lo), "v"(w)); \
-                asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #r_ " row_mask:0xf bank_mask:0xf" : "+v"(acc[s][16 + r_]) : "v"(hi), "v"(w));
-                asm volatile("s_nop 1" ::: "memory");
-                NF_ROW_FMA(0) NF_ROW_FMA(1) NF_ROW_FMA(2) NF_ROW_FMA(3) NF_ROW_FMA(4) NF_ROW_FMA(5) NF_ROW_FMA(6) NF_ROW_FMA(7)
-                NF_ROW_FMA(8) NF_ROW_FMA(9) NF_ROW_FMA(10) NF_ROW_FMA(11) NF_ROW_FMA(12) NF_ROW_FMA(13) NF_ROW_FMA(14) NF_ROW_FMA(15)
-#undef NF_ROW_FMA
-            }
+            for (int s = 0; s < NSTEP; ++s)
+                acc[s] = __builtin_amdgcn_mfma_f32_32x32x1f32(wcur[s], b[s * IR], acc[s], 0, 0, 0);
         }
         {
             // (each weight register is reloaded for the next round right after its use)
@@ -344,13 +337,24 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) wcur[s] = g.wt[s][wrow];
         }
-        if (tid == j + 1) {                             // unit j+1's sums over units <= j-1, for wave 0's next round
+        if (wave == ((j + 1) >> 6)) {                   // unit j+1's sums over units <= j-1, for wave 0's next round
+            const int v = (j + 1) & 63, row = v & 31;
+            const int r = 16 * (v >> 5) + (row & 3) + 4 * (row >> 3);       // its register; lanes of half (row >> 2) & 1
+            float ex[NSTEP];
+#define NF_EX(R_) case R_: _Pragma("unroll") for (int s = 0; s < NSTEP; ++s) ex[s] = acc[s][R_]; break;
+            switch (r) {
+                NF_EX(0) NF_EX(1) NF_EX(2) NF_EX(3) NF_EX(4) NF_EX(5) NF_EX(6) NF_EX(7) NF_EX(8) NF_EX(9) NF_EX(10)
+                NF_EX(11) NF_EX(12) NF_EX(13) NF_EX(14) NF_EX(15) NF_EX(16) NF_EX(17) NF_EX(18) NF_EX(19) NF_EX(20)
+                NF_EX(21) NF_EX(22) NF_EX(23) NF_EX(24) NF_EX(25) NF_EX(26) NF_EX(27) NF_EX(28) NF_EX(29) NF_EX(30)
+                default:
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s)
+                    for (int s = 0; s < NSTEP; ++s) ex[s] = acc[s][31];
+            }
+#undef NF_EX
+            if (((tid >> 5) & 1) == ((row >> 2) & 1)) {
 #pragma unroll
-                for (int r = 0; r < IR; r += 4)
-                    *reinterpret_cast<float4*>(sh + ((par ^ 1) * MAXSTEP + s) * IR + r) =
-                        make_float4(acc[s][r], acc[s][r + 1], acc[s][r + 2], acc[s][r + 3]);
+                for (int s = 0; s < NSTEP; ++s) sh[((par ^ 1) * MAXSTEP + s) * IR + (tid & 31)] = ex[s];
+            }
         }
     STAMP(3)
         if (wave >= 4) product();
