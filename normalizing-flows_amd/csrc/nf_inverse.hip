@@ -171,11 +171,17 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                 rs[9] = g.wl[(int64_t)(j < H ? j + 1 : H) * 64 + lane];      // next round's weight rows
             }
             STAMP(0)
+            float y, ld;
+            int bin;
+            typedef const __attribute__((address_space(3))) float* lds_ptr;
+            if constexpr (KT > 0) {
+                // lanes 32..63 build the width knots of the sample of lane - 32 (see rqs_inverse_pair)
+                const float zin = __shfl(rs[7], arow);
+                rqs_inverse_pair<KT, PSTR, lds_ptr>((lds_ptr)(prm + arow), zin, g.c, lane >= IR, y, ld, bin);
+            }
             if (lane < IR) {
                 const int64_t row = (m0 + tid < g.B) ? m0 + tid : g.B - 1;
                 const bool row_ok = m0 + tid < g.B;
-                float y, ld;
-                int bin;
 #ifdef NF_NOEVAL
                 y = prm[tid] + rs[7]; ld = prm[tid + PSTR]; bin = 0;
 #else
@@ -187,8 +193,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                     y = (rs[7] - shift) / scale;
                     ld = -logf(scale);
                     bin = 0;
-                } else {
-                    typedef const __attribute__((address_space(3))) float* lds_ptr;
+                } else if constexpr (KT == 0) {
                     rqs_eval<KT, true, PSTR, false, false, lds_ptr>((lds_ptr)(prm + tid), rs[7], g.c, y, ld, bin);
                 }
 #endif

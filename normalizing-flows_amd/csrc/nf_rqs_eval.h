@@ -224,6 +224,98 @@ __device__ __forceinline__ void rqs_eval(PT p, float x, const RqsConst& a, float
 }
 
 
+// Inverse of one element per lane PAIR: lanes l and l + 32 of a wave (all 64 lanes active, same p and x in both).
+// The softmax and the knot prefix sums are the long, identical part of the work for widths and heights, so the lanes
+// with `widths` set build the width knots while their partners build the height knots on the same instruction
+// stream; the partners search the bin, fetch the two width knots of that bin by lane exchange and finish.  Same
+// operations in the same order as rqs_eval<KT, true> (pre_div = 1): y, ld, bin are valid in the lanes with
+// widths == false.
+template <int KT, int STRIDE, class PT>
+__device__ __forceinline__ void rqs_inverse_pair(PT p, float x, const RqsConst& a, bool widths, float& y, float& ld,
+                                                 int& bin) {
+    static_assert(KT > 0, "bin count must be a template constant");
+    constexpr int K = KT;
+    const bool outside = a.tails && !(x >= a.left && x <= a.right);
+    const float x_in = x;
+    x = outside ? 0.5f * (a.left + a.right) : x;
+    const PT u = p + (widths ? 0 : K * STRIDE);
+    const PT ud = p + 2 * K * STRIDE;
+    const float mn = widths ? a.min_w : a.min_h, sc = widths ? a.scale_w : a.scale_h;
+    float e[K];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        e[k] = u[k * STRIDE];
+        m = fmaxf(m, e[k]);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        e[k] = nf_exp(e[k] - m);
+        s += e[k];
+    }
+    const float r = nf_rcp(s);
+    double accd = 0.0;
+    float kn[K + 1];
+    kn[0] = a.left;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float w = mn + sc * (e[k] * r);
+        accd += (double)w;
+        kn[k + 1] = a.span * (float)accd + a.left;
+    }
+    kn[K] = a.right;
+    // bin of x among this lane's knots (meaningful in the height lanes)
+    int b = 0;
+    float y0 = kn[0], y1 = kn[1];
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (x >= kn[k]) { b = k; y0 = kn[k]; y1 = kn[k + 1]; }
+    // the width lanes pick the knots of their partner's bin and hand them over
+    const int bpartner = __shfl_xor(b, 32);          // (unconditional: a lane exchange inside a divergent branch reads inactive lanes)
+    const int bsel = widths ? bpartner : b;
+    float x0 = kn[0], x1 = kn[1];
+#pragma unroll
+    for (int k = 1; k < K; ++k)
+        if (bsel == k) { x0 = kn[k]; x1 = kn[k + 1]; }
+    x0 = __shfl_xor(x0, 32);
+    x1 = __shfl_xor(x1, 32);
+
+    float u0, u1;
+    if (a.tails) {
+        u0 = b == 0 ? a.tail_const : ud[(b - 1) * STRIDE];
+        u1 = b == K - 1 ? a.tail_const : ud[b * STRIDE];
+    } else {
+        u0 = ud[b * STRIDE];
+        u1 = ud[(b + 1) * STRIDE];
+    }
+    const float d0 = a.min_d + softplus_f(u0);
+    const float d1 = a.min_d + softplus_f(u1);
+    const float bw = x1 - x0;
+    const float bh = y1 - y0;
+    const float sl = bh / bw;
+    const float curv = d0 + d1 - 2.0f * sl;
+    const float dy = x - y0;
+    const float qa = dy * curv + bh * (sl - d0);
+    const float qb = bh * d0 - dy * curv;
+    const float qc = -sl * dy;
+    const float disc = qb * qb - 4.0f * qa * qc;
+    const float t = (2.0f * qc) / (-qb - sqrtf(disc));
+    y = t * bw + x0;
+    const float t1mt = t * (1.0f - t);
+    const float den = sl + curv * t1mt;
+    const float omt = 1.0f - t;
+    const float dnum = (sl * sl) * (d1 * (t * t) + 2.0f * sl * t1mt + d0 * (omt * omt));
+    ld = -(nf_log(dnum) - 2.0f * nf_log(den));
+    bin = b;
+    if (outside) {
+        y = x_in;
+        ld = 0.0f;
+        bin = -1;
+    }
+}
+
+
 // ---- backward (forward direction of the spline): d(y, ld)/d(x, params) --------------------------------
 // Recomputes the forward quantities from (x, params) instead of saving ~10 intermediates per element
 // (what autograd keeps for the reference's op sequence), then overwrites the element's P parameters in
