@@ -9,14 +9,16 @@
 // The samples never interact, so a workgroup keeps 32 samples from x[0] to x[H] without any grid-wide step,
 // as a software pipeline with ONE barrier per feature ("round" j = feature j / unit j):
 //
-//   wave 0, lanes = samples (the critical path): completes the parameters of feature j (bulk part from LDS +
-//     the rank-1 terms of the two newest hidden units), inverts the spline (nf_rqs_eval.h, the code the forward
-//     kernels use), then finishes unit j of every hidden layer for its sample - a chain of NSTEP scalar FMAs,
-//     because everything older than unit j-1 is already summed in a partial that unit j's owner exported a
-//     round earlier - and publishes x[j], unit j's activations and its final hidden value through LDS.
-//   all threads, one round behind (thread k owns unit k of every hidden layer: NSTEP x 32 running sums in
-//     registers, "right-looking"): add unit j-1's activations times one weight each (transposed pack: a 2 KB
-//     coalesced weight row per layer and round, reloaded a round ahead); thread j+1 exports its sums.
+//   wave 0 (the critical path): completes the parameters of feature j (bulk part from LDS + the rank-1 terms of
+//     the two newest hidden units, one MFMA), inverts the spline (nf_rqs_eval.h: lanes 0..31 = samples, lanes
+//     32..63 build the width knots of the same samples), then finishes unit j of every hidden layer for its
+//     sample - a chain of NSTEP scalar FMAs, because everything older than unit j-1 is already summed in a partial
+//     that unit j's owner exported a round earlier - and publishes x[j], unit j's activations and its final hidden
+//     value through LDS.
+//   all waves, one round behind ("right-looking"): wave w owns units 64w..64w+63 of every hidden layer, their
+//     running sums for the 32 samples in MFMA accumulator layout (NSTEP x 32 registers); unit j-1's activations
+//     enter as one rank-1 v_mfma_f32_32x32x1_2b_f32 per layer (weights: transposed pack, a 2 KB coalesced row per
+//     layer and round, reloaded a round ahead); the wave holding unit j+1 exports its sums.
 //   waves 1..7, "left-looking": the final-layer row block of feature j+2 over hidden units 0..j-1, a
 //     32 x 32 x j product on v_mfma_f32_32x32x2_f32 with K split over the waves (weights packed per feature in
 //     operand order, triangular: only the live K range is stored and read); the partial tiles of the
