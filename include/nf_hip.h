@@ -237,7 +237,7 @@ int nf_resnet_hidden_fwd(const float* x, int64_t x_row_stride, const int32_t* in
 /* ---- autoregressive inverse, row-resident (replaces the D conditioner passes of transforms.py:493-500
  *      for MaskedPiecewiseRationalQuadraticAutoregressiveTransform, made.py:352-359 + rational_quadratic.py) ----
  * Requires hidden units in degree order (unit j has MADE degree j+1 in every hidden layer: the reference's
- * non-random masks with hidden <= features - 1, made.py:142-146), ReLU, no BatchNorm / context, and
+ * non-random masks with hidden <= features - 1, made.py:142-146), ReLU, BatchNorm folded (eval mode), no context, and
  * P = 3K-1 (linear tails) or 3K+1 <= 32 parameters per feature.  One workgroup carries 32 samples through
  * features 0..hidden; total work about one forward pass (see nf_inverse.hip). */
 int nf_made_rqs_inverse_rows_supported(int features, int hidden, int n_steps, int K, int tails);
@@ -247,8 +247,9 @@ int nf_made_rqs_inverse_rows_supported(int features, int hidden, int n_steps, in
  *   bf[H+1][32]: final-layer bias of feature f, parameters 0..P-1, zero padded
  *   wl[H+1][2][32]: wl[f][0][c] = weight[f*P + c][f-1] * mask, wl[f][1][c] = weight[f*P + c][f-2] * mask: the two
  *       newest hidden units feature f reads (zero where there is none)
- *   dg[H][16]: unit j of hidden step s: dg[j][s] = its weight on unit j of step s-1 (s = 0: on input j),
- *       dg[j][8 + s] = its weight on unit j-1 (zero for j = 0), mask applied
+ *   dg[H][32]: unit j of hidden step s: dg[j][s] = its weight on unit j of step s-1 (s = 0: on input j),
+ *       dg[j][8 + s] = its weight on unit j-1 (zero for j = 0), mask applied; dg[j][16 + s], dg[j][24 + s] = scale /
+ *       shift of the eval-mode BatchNorm on the input of step s (made.py:271-277), 1 / 0 without BatchNorm
  *   wf[T][64][4], features 0..H back to back (feature f starts at super-step sum over g < f of ceil(g/8)):
  *       for feature f, K super-step S < ceil(f/8), lane (kh = lane>>5, col = lane&31):
  *       weight[f*P + col][8S + 4kh + 0..3] * mask (zero for col >= P and for the units f-2, f-1 kept in wl) */

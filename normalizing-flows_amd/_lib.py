@@ -464,7 +464,8 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
 
 class PackedInverse:
     """Parameter blob of nf_made_rqs_inverse_rows (layout: include/nf_hip.h) for a MADE whose hidden units are in
-    degree order.  `steps` = [(weight, mask, bias, flags)] of the hidden stack, then the final layer."""
+    degree order.  `steps` = [(weight, mask, bias, flags, (bn_scale, bn_shift) or None)] of the hidden stack, then
+    the final layer."""
     __slots__ = ('hidden', 'features', 'P', 'K', 'tails', 'n_steps', 'flags', 'blob')
 
     def __init__(self, steps, final_weight, final_mask, final_bias, features, num_bins, tails):
@@ -479,7 +480,7 @@ class PackedInverse:
         HS = (H + 63) // 64 * 64
         dev = final_weight.device
         parts, flags = [], []
-        for w, m, b, fl in steps:
+        for w, m, b, fl, _ in steps:
             w = _dev(w.detach(), 'weight')
             wm = w if m is None else w * m
             wt = torch.zeros((H + 1, HS), dtype=torch.float32, device=dev)
@@ -503,13 +504,18 @@ class PackedInverse:
         wl[2:, 1, :P] = wf[idx[1:], :, idx[1:] - 2]
         parts.append(wl.reshape(-1))
         # hidden layers, unit j: dg[j][s] = step s's weight on unit j of the step before (s = 0: on input j),
-        # dg[j][8 + s] = its weight on unit j-1
-        dg = torch.zeros((H, 16), dtype=torch.float32, device=dev)
+        # dg[j][8 + s] = its weight on unit j-1, dg[j][16 + s] / [24 + s] = the eval-BatchNorm scale / shift applied
+        # to unit j of step s-1 on its way into step s (1 / 0 without BatchNorm)
+        dg = torch.zeros((H, 32), dtype=torch.float32, device=dev)
+        dg[:, 16:24] = 1.0
         ar = torch.arange(H, device=dev)
-        for s, (w, m, b, fl) in enumerate(steps):
+        for s, (w, m, b, fl, bn) in enumerate(steps):
             wm = w.detach() if m is None else w.detach() * m
             dg[:, s] = wm[ar, ar]
             dg[1:, 8 + s] = wm[ar[1:], ar[:-1]]
+            if bn is not None:
+                dg[:, 16 + s] = bn[0].detach()
+                dg[:, 24 + s] = bn[1].detach()
         parts.append(dg.reshape(-1))
         nss = (torch.arange(H + 2, device=dev) + 7) // 8                  # super-steps of feature f
         ns_max = (H + 7) // 8

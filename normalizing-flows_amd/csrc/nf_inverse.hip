@@ -70,7 +70,8 @@ struct InvArgs {
     const float* bias[MAXSTEP];   // [HS]
     const float* bf;              // [H+1][32] final-layer bias of features 0..H, columns >= P zero
     const float* wl;              // [H+1][2][32] wl[f][0][c] = W[f*P+c][f-1], wl[f][1][c] = W[f*P+c][f-2]
-    const float* dg;              // [H][16] unit j: [s] = step s's weight on unit j of the step before, [8+s] = on unit j-1
+    const float* dg;              // [H][32] unit j: [s] = step s's weight on unit j of the step before, [8+s] = on unit j-1,
+                                  //         [16+s], [24+s] = eval-BatchNorm scale / shift on the input of step s (1 / 0 without)
     const float4* wf;             // [super-step][lane]: lane (kh, col) holds W[f*P+col][8S+4kh .. +3], units >= f-2 zeroed
     int flags[MAXSTEP];
     int64_t B;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
     for (int i = 0; i < 12; ++i) rs[i] = 0.0f;
     if (wave == 0) {
         rs[7] = tid < IR ? g.z[((m0 + tid < g.B) ? m0 + tid : g.B - 1) * g.ldz] : 0.0f;
-        rs[5] = g.dg[tid & 15];
+        rs[5] = g.dg[tid & 31];
         rs[9] = g.wl[lane];
     } else if (wave <= 4) {                 // parameter sums: columns 4 (tid & 7) .. + 3 of one sample
         const float4 nb = *reinterpret_cast<const float4*>(g.bf + 32 + ((tid * 4) & 31));
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                 STAMP(1)
                 if (j < H) {
                     rs[7] = g.z[row * g.ldz + j + 1];
-                    // unit j's weights on itself (lanes 0..7 of the record) and on unit j-1 (lanes 8..15), one per step
+                    // unit j's record: weights on itself (lanes 0..7) and on unit j-1 (8..15), BatchNorm scale / shift (16.., 24..)
                     const int rec = __float_as_int(rs[5]);
                     // running sums of unit j: its owner's export (units <= j-2) + unit j-1's term
                     float cur[NSTEP];
@@ -223,7 +224,10 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                     val[0] = fmaf(__int_as_float(__builtin_amdgcn_readlane(rec, 0)), y, cur[0]);
 #pragma unroll
                     for (int s = 1; s < NSTEP; ++s) {
-                        rs[s] = (g.flags[s] & F_RELU_IN) ? fmaxf(val[s - 1], 0.0f) : val[s - 1];
+                        // input of step s: (eval-mode BatchNorm, folded to scale / shift, then) ReLU of unit j one step back
+                        const float bn = fmaf(val[s - 1], __int_as_float(__builtin_amdgcn_readlane(rec, 16 + s)),
+                                              __int_as_float(__builtin_amdgcn_readlane(rec, 24 + s)));
+                        rs[s] = (g.flags[s] & F_RELU_IN) ? fmaxf(bn, 0.0f) : bn;
                         val[s] = fmaf(__int_as_float(__builtin_amdgcn_readlane(rec, s)), rs[s], cur[s]);
                         if (s >= 2 && (g.flags[s] & F_RESIDUAL)) val[s] += val[s >= 2 ? s - 2 : 0];
                         if (g.flags[s] & F_RELU_OUT) val[s] = fmaxf(val[s], 0.0f);
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                     for (int s = 0; s < NSTEP; ++s) bc[(par * MAXSTEP + s) * IR + tid] = rs[s];
                     hlT[j * IR + tid] = val[NSTEP - 1];
                     rs[6] = val[NSTEP - 1];
-                    rs[5] = g.dg[(int64_t)(j + 1 < H ? j + 1 : H - 1) * 16 + (tid & 15)];
+                    rs[5] = g.dg[(int64_t)(j + 1 < H ? j + 1 : H - 1) * 32 + (tid & 31)];
                 }
                 STAMP(2)
             }
@@ -414,7 +418,7 @@ extern "C" int nf_made_rqs_inverse_rows_supported(int features, int hidden, int 
 extern "C" size_t nf_made_inverse_blob_floats(int hidden, int n_steps) {
     if (hidden <= 0 || hidden > IT || n_steps < 1 || n_steps > MAXSTEP) return 0;
     const size_t H = hidden, HS = hs_of(hidden);
-    return n_steps * (H + 1) * HS + 3 * (H + 1) * 32 + H * 16 + (size_t)total_supersteps(hidden) * 256;
+    return n_steps * (H + 1) * HS + 3 * (H + 1) * 32 + H * 32 + (size_t)total_supersteps(hidden) * 256;
 }
 
 static int inverse_rows_impl(const float* blob, int hidden, int n_steps, const int* step_flags, const float* z,
@@ -441,7 +445,7 @@ static int inverse_rows_impl(const float* blob, int hidden, int n_steps, const i
     }
     g.bf = p; p += (size_t)(H + 1) * 32;
     g.wl = p; p += (size_t)(H + 1) * 64;
-    g.dg = p; p += (size_t)H * 16;
+    g.dg = p; p += (size_t)H * 32;
     g.wf = reinterpret_cast<const float4*>(p);
     g.z = z; g.ldz = z_row_stride; g.x = x; g.ldx = x_row_stride; g.hid = hidden_out; g.ldh = h_row_stride;
     g.partial = workspace; g.B = B; g.H = H; g.HS = HS;

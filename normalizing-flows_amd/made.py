@@ -348,11 +348,16 @@ class MADE(nn.Module):
         """Parameter blob for the row-resident inverse kernel (nf_made_rqs_inverse_rows; num_bins None: the affine
         variant nf_made_affine_inverse_rows), or None when this
         network is outside its scope: hidden units must be in degree order in every layer (the non-random masks
-        with hidden_features <= features - 1), no BatchNorm, the step structure of hidden_program()."""
+        with hidden_features <= features - 1), BatchNorm in eval mode only, the step structure of hidden_program()."""
         steps, _ = self.hidden_program()
         layers = [st[0] for st in steps] + [self.final_layer]
         key = tuple((l.weight._version, l.weight.data_ptr(), None if l.bias is None else l.bias._version,
                      l.mask._version) for l in layers) + (self.final_layer.weight.device, num_bins, tails)
+        for st in steps:
+            if st[6] is not None:
+                bn = st[6]
+                key += (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+                        bn.training)
         cached = getattr(self, '_inverse_rows_cache', None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -363,11 +368,13 @@ class MADE(nn.Module):
         flags = []
         want = torch.arange(1, H + 1)
         for i, (layer, src, dst, res, relu_in, relu_out, bn) in enumerate(steps):
-            ok = ok and bn is None and torch.equal(layer.degrees.cpu(), want)
+            ok = ok and (bn is None or (i > 0 and not bn.training)) and torch.equal(layer.degrees.cpu(), want)
             ok = ok and (i == 0 or src == steps[i - 1][2]) and (res is None or (i >= 2 and res == steps[i - 2][2]))
             flags.append((1 if relu_in else 0) | (2 if res is not None else 0) | (4 if relu_out else 0))
         if ok:
-            pack = _lib.PackedInverse([(st[0].weight, st[0].mask, st[0].bias, fl) for st, fl in zip(steps, flags)],
+            pack = _lib.PackedInverse([(st[0].weight, st[0].mask, st[0].bias, fl,
+                                        None if st[6] is None else _bn_scale_shift(st[6]))
+                                       for st, fl in zip(steps, flags)],
                                       self.final_layer.weight, self.final_layer.mask, self.final_layer.bias, D,
                                       num_bins, tails)
         object.__setattr__(self, '_inverse_rows_cache', (key, pack))

@@ -326,10 +326,11 @@ def test_rq_ar_incremental_inverse_equals_d_pass_loop(nf, tol=1e-5):
 ROW_CASES = [dict(D=100, H=64, K=8, B=70), dict(D=300, H=136, K=4, B=33), dict(D=784, H=512, K=8, B=45),
              dict(D=65, H=64, K=8, B=32), dict(D=90, H=40, K=10, B=64, residual=False, blocks=3),
              dict(D=90, H=48, K=5, B=31, blocks=1), dict(D=50, H=24, K=6, B=40, tails=None),
-             dict(D=40, H=16, K=8, B=1, residual=False, blocks=1)]
+             dict(D=40, H=16, K=8, B=1, residual=False, blocks=1),
+             dict(D=120, H=64, K=8, B=50, bn=True), dict(D=90, H=40, K=8, B=20, residual=False, blocks=2, bn=True)]
 
 
-@pytest.mark.parametrize('case', ROW_CASES, ids=lambda c: 'D%d_H%d_K%d' % (c['D'], c['H'], c['K']))
+@pytest.mark.parametrize('case', ROW_CASES, ids=lambda c: 'D%d_H%d_K%d%s' % (c['D'], c['H'], c['K'], '_bn' if c.get('bn') else ''))
 def test_rq_ar_row_resident_inverse(nf, case, tol=3e-5):
     """nf_made_rqs_inverse_rows (32 samples per workgroup from feature 0 to H in one launch) against the windowed
     incremental inverse, which the test above ties to the reference's D-pass loop; plus the round trip.  The two
@@ -342,10 +343,16 @@ def test_rq_ar_row_resident_inverse(nf, case, tol=3e-5):
     tails = case.get('tails', 'linear')
     t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
         D, H, num_bins=K, tails=tails, tail_bound=3., num_blocks=case.get('blocks', 2),
-        use_residual_blocks=case.get('residual', True)).cuda().eval()
+        use_residual_blocks=case.get('residual', True), use_batch_norm=case.get('bn', False)).cuda().eval()
     with torch.no_grad():
         for p in t.parameters():
             p.mul_(1.5)
+        for m in t.modules():                       # eval-mode BatchNorm with non-trivial statistics
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
         z = torch.randn(B, D, device='cuda') * 1.5 if tails else torch.rand(B, D, device='cuda')
         assert t.autoregressive_net.inverse_rows_pack(K, tails) is not None
         fast_x, fast_ld = t.inverse(z)
@@ -411,11 +418,14 @@ def test_rq_ar_row_resident_inverse_strides_and_chunks(nf):
 
 
 def test_rq_ar_row_resident_inverse_scope(nf):
-    """Networks the row-resident kernel does not cover keep the windowed path: wrap-around degrees, BatchNorm."""
+    """Networks the row-resident kernel does not cover keep the windowed path: wrap-around degrees, BatchNorm in
+    train() mode, more parameters per feature than one 32-column block."""
     mk = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform
     assert mk(40, 64, num_bins=8, tails='linear').cuda().autoregressive_net.inverse_rows_pack(8, 'linear') is None
-    assert mk(100, 64, num_bins=8, tails='linear', use_batch_norm=True).cuda().eval() \
+    assert mk(100, 64, num_bins=8, tails='linear', use_batch_norm=True).cuda().train() \
         .autoregressive_net.inverse_rows_pack(8, 'linear') is None
+    assert mk(100, 64, num_bins=8, tails='linear', use_batch_norm=True).cuda().eval() \
+        .autoregressive_net.inverse_rows_pack(8, 'linear') is not None
     assert mk(100, 64, num_bins=16, tails='linear').cuda().autoregressive_net.inverse_rows_pack(16, 'linear') is None
 
 
