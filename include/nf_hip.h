@@ -258,10 +258,15 @@ size_t nf_made_inverse_blob_floats(int hidden, int n_steps);
  * workspace = the [tiles][B] logdet partials of nf_made_rqs_fwd_tiles (tiles wholly below feature hidden+1
  * are written).  The caller finishes features hidden+1.. with nf_made_rqs_fwd_tiles(tile_begin =
  * (hidden+1) / features_per_tile, reduce = 1).  step_flags[s]: 1 = ReLU on the step's input, 2 = add the
- * output of step s-2 (residual block), 4 = ReLU on the step's output (feed-forward block). */
+ * output of step s-2 (residual block), 4 = ReLU on the step's output (feed-forward block).
+ * Context-conditioned MADE (made.py:354-355, :279-283): context_term[b, :] = context_layer(context) is added to the
+ * initial layer's output, gate0 / gate1 [b, :] = sigmoid(block.context_layer(context)) scale the second layer of
+ * residual block 0 / 1 before the skip connection; all [B, hidden] with row stride context_row_stride, NULL without a
+ * context. */
 int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags, const float* z,
                              int64_t z_row_stride, float* x, int64_t x_row_stride, float* hidden_out,
-                             int64_t h_row_stride, float* workspace, size_t workspace_bytes, int64_t B, int features,
+                             int64_t h_row_stride, const float* context_term, const float* gate0, const float* gate1,
+                             int64_t context_row_stride, float* workspace, size_t workspace_bytes, int64_t B, int features,
                              int K, int tails, double tail_bound, double min_bin_width, double min_bin_height,
                              double min_derivative, void* stream);
 
@@ -272,7 +277,8 @@ int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const i
 int nf_made_affine_inverse_rows_supported(int features, int hidden, int n_steps);
 int nf_made_affine_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags, const float* z,
                                 int64_t z_row_stride, float* x, int64_t x_row_stride, float* hidden_out,
-                                int64_t h_row_stride, int64_t B, int features, void* stream);
+                                int64_t h_row_stride, const float* context_term, const float* gate0, const float* gate1,
+                                int64_t context_row_stride, int64_t B, int features, void* stream);
 
 /* ---- affine transform (replaces transforms.py:328-347 coupling, :540-566 autoregressive) -------- */
 

@@ -97,13 +97,14 @@ _SIGNATURES = {
     'nf_made_rqs_inverse_rows_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'nf_made_inverse_blob_floats': (_c.c_size_t, [_c.c_int, _c.c_int]),
     'nf_made_rqs_inverse_rows': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64,
-                                            _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_size_t,
+                                            _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
+                                            _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_size_t,
                                             _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double,
                                             _c.c_double, _c.c_double, _c.c_void_p]),
     'nf_made_affine_inverse_rows_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_made_affine_inverse_rows': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64,
-                                               _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int,
-                                               _c.c_void_p]),
+                                               _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
+                                               _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p]),
     'nf_made_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -544,8 +545,28 @@ def made_affine_inverse_rows_supported(features, hidden, n_steps):
     return load().nf_made_affine_inverse_rows_supported(int(features), int(hidden), int(n_steps)) == 1
 
 
-def made_affine_inverse_rows(pi, z, out, hidden):
-    """Features 0..H of the affine autoregressive inverse and the final hidden state (nf_made_affine_inverse_rows)."""
+def _context_args(ctx, B, hidden):
+    """(context term, gate of block 0, gate of block 1) [B, hidden] tensors -> pointers + common row stride."""
+    if ctx is None:
+        return None, None, None, 0
+    stride = None
+    ptrs = []
+    for t in ctx:
+        if t is None:
+            ptrs.append(None)
+            continue
+        _dev(t, 'context term')
+        p, s = _rows(t, 'context term')
+        if t.shape != (B, hidden) or (stride is not None and s != stride):
+            raise ValueError('context terms must be [B,%d] tensors with one row stride' % hidden)
+        stride = s
+        ptrs.append(p)
+    return ptrs[0], ptrs[1], ptrs[2], stride
+
+
+def made_affine_inverse_rows(pi, z, out, hidden, ctx=None):
+    """Features 0..H of the affine autoregressive inverse and the final hidden state (nf_made_affine_inverse_rows).
+    ctx: None or (context term, gate0, gate1) as _context_args takes them."""
     lib = load()
     _dev(z, 'inputs')
     _dev(out, 'outputs')
@@ -557,16 +578,18 @@ def made_affine_inverse_rows(pi, z, out, hidden):
     if pi.P != 2 or z.shape[1] != pi.features or out.shape != z.shape or hidden.shape != (B, pi.hidden):
         raise ValueError('Expected an affine pack, inputs / outputs [B,%d] and hidden [B,%d]' % (pi.features, pi.hidden))
 
+    c0, g0, g1, cs = _context_args(ctx, B, pi.hidden)
+
     def launch():
         return lib.nf_made_affine_inverse_rows(pi.blob.data_ptr(), pi.hidden, pi.n_steps, pi.flags, zp, zs, xp, xs, hp,
-                                               hs, B, pi.features, _stream())
+                                               hs, c0, g0, g1, cs, B, pi.features, _stream())
     with torch.cuda.device(z.device):
         code = launch() if _timer is None else _timer.record(('made_affine_inverse_rows', pi.hidden, pi.features, B), launch)
         _check(code, 'nf_made_affine_inverse_rows')
 
 
 def made_rqs_inverse_rows(pi, z, out, hidden, workspace, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,
-                          min_derivative=1e-3):
+                          min_derivative=1e-3, ctx=None):
     """Features 0..H of the autoregressive inverse for every row of z (nf_made_rqs_inverse_rows); leaves the final
     hidden state in `hidden` and the logdet partials of the finished fused tiles in `workspace`."""
     lib = load()
@@ -580,9 +603,11 @@ def made_rqs_inverse_rows(pi, z, out, hidden, workspace, tail_bound, min_bin_wid
     if z.shape[1] != pi.features or out.shape != z.shape or hidden.shape != (B, pi.hidden):
         raise ValueError('Expected inputs / outputs [B,%d] and hidden [B,%d]' % (pi.features, pi.hidden))
 
+    c0, g0, g1, cs = _context_args(ctx, B, pi.hidden)
+
     def launch():
         return lib.nf_made_rqs_inverse_rows(pi.blob.data_ptr(), pi.hidden, pi.n_steps, pi.flags, zp, zs, xp, xs, hp, hs,
-                                            workspace.data_ptr(), workspace.numel() * 4, B, pi.features, pi.K,
+                                            c0, g0, g1, cs, workspace.data_ptr(), workspace.numel() * 4, B, pi.features, pi.K,
                                             pi.tails, float(tail_bound), float(min_bin_width), float(min_bin_height),
                                             float(min_derivative), _stream())
     with torch.cuda.device(z.device):

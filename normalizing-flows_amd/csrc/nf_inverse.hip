@@ -73,6 +73,9 @@ struct InvArgs {
     const float* dg;              // [H][32] unit j: [s] = step s's weight on unit j of the step before, [8+s] = on unit j-1,
                                   //         [16+s], [24+s] = eval-BatchNorm scale / shift on the input of step s (1 / 0 without)
     const float4* wf;             // [super-step][lane]: lane (kh, col) holds W[f*P+col][8S+4kh .. +3], units >= f-2 zeroed
+    const float* ctx0;            // nullable [B][ldc]: context term added to the initial layer's output (made.py:354-355)
+    const float* gate[2];         // nullable [B][ldc]: sigmoid gates of the residual blocks' second layer (made.py:279-283)
+    int64_t ldc;
     int flags[MAXSTEP];
     int64_t B;
     int H, HS, fpt, full_tiles;
@@ -119,14 +122,21 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
     // Per-role state in one register array (wave 0 never runs the bulk product, the others never invert splines):
     //   wave 0:     rs[0..NSTEP) = activations of the unit finished last round, rs[5] = next unit's weight record,
     //               rs[6] = final hidden value of unit j-1, rs[7] = next input z, rs[8] = running logdet sum,
-    //               rs[9] = next feature's two newest-unit weight rows (lane = [row][column])
+    //               rs[9] = next feature's two newest-unit weight rows (lane = [row][column]),
+    //               rs[10], rs[11] = next unit's context gates (residual blocks), rs[12] = its context term
     //   waves 1..7: rs[0..4) = next feature's bias, four columns (waves 1..4), rs[4..12) = next round's first two B operands
-    float rs[12];
+    float rs[13];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) rs[i] = 0.0f;
+    for (int i = 0; i < 13; ++i) rs[i] = 0.0f;
     if (wave == 0) {
         rs[7] = tid < IR ? g.z[((m0 + tid < g.B) ? m0 + tid : g.B - 1) * g.ldz] : 0.0f;
         rs[5] = g.dg[tid & 31];
+        if (g.ctx0 && tid < IR) {
+            const int64_t crow = ((m0 + tid < g.B) ? m0 + tid : g.B - 1) * g.ldc;
+            rs[12] = g.ctx0[crow];
+            if (g.gate[0]) rs[10] = g.gate[0][crow];
+            if (g.gate[1]) rs[11] = g.gate[1][crow];
+        }
         rs[9] = g.wl[lane];
     } else if (wave <= 4) {                 // parameter sums: columns 4 (tid & 7) .. + 3 of one sample
         const float4 nb = *reinterpret_cast<const float4*>(g.bf + 32 + ((tid * 4) & 31));
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                     float val[NSTEP];
                     rs[0] = y;
                     val[0] = fmaf(__int_as_float(__builtin_amdgcn_readlane(rec, 0)), y, cur[0]);
+                    if (g.ctx0) val[0] += rs[12];
 #pragma unroll
                     for (int s = 1; s < NSTEP; ++s) {
                         // input of step s: (eval-mode BatchNorm, folded to scale / shift, then) ReLU of unit j one step back
@@ -229,7 +240,11 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                                               __int_as_float(__builtin_amdgcn_readlane(rec, 24 + s)));
                         rs[s] = (g.flags[s] & F_RELU_IN) ? fmaxf(bn, 0.0f) : bn;
                         val[s] = fmaf(__int_as_float(__builtin_amdgcn_readlane(rec, s)), rs[s], cur[s]);
-                        if (s >= 2 && (g.flags[s] & F_RESIDUAL)) val[s] += val[s >= 2 ? s - 2 : 0];
+                        if (s >= 2 && (g.flags[s] & F_RESIDUAL)) {
+                            // x + t, or with a context x + t * sigmoid(context layer) (made.py:279-283)
+                            const float t = g.gate[s >= 4 ? 1 : 0] ? val[s] * rs[s >= 4 ? 11 : 10] : val[s];
+                            val[s] = val[s >= 2 ? s - 2 : 0] + t;
+                        }
                         if (g.flags[s] & F_RELU_OUT) val[s] = fmaxf(val[s], 0.0f);
                     }
 #pragma unroll
@@ -237,6 +252,12 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                     hlT[j * IR + tid] = val[NSTEP - 1];
                     rs[6] = val[NSTEP - 1];
                     rs[5] = g.dg[(int64_t)(j + 1 < H ? j + 1 : H - 1) * 32 + (tid & 31)];
+                    if (g.ctx0) {
+                        const int64_t cnext = row * g.ldc + (j + 1 < H ? j + 1 : H - 1);
+                        rs[12] = g.ctx0[cnext];
+                        if (g.gate[0]) rs[10] = g.gate[0][cnext];
+                        if (g.gate[1]) rs[11] = g.gate[1][cnext];
+                    }
                 }
                 STAMP(2)
             }
@@ -423,10 +444,13 @@ extern "C" size_t nf_made_inverse_blob_floats(int hidden, int n_steps) {
 
 static int inverse_rows_impl(const float* blob, int hidden, int n_steps, const int* step_flags, const float* z,
                              int64_t z_row_stride, float* x, int64_t x_row_stride, float* hidden_out,
-                             int64_t h_row_stride, float* workspace, int64_t B, int features, int K, const RqsConst& c,
-                             void* stream) {
+                             int64_t h_row_stride, const float* context_term, const float* gate0, const float* gate1,
+                             int64_t context_row_stride, float* workspace, int64_t B, int features, int K,
+                             const RqsConst& c, void* stream) {
     if (B == 0) return NF_OK;
     if (!blob || !step_flags || !z || !x || !hidden_out) return NF_ERR_NULL;
+    if ((gate0 || gate1) && !context_term) return NF_ERR_NULL;
+    if (context_term && context_row_stride < hidden) return NF_ERR_LAYOUT;
     if (z_row_stride < features || x_row_stride < features || h_row_stride < hidden || ((uintptr_t)blob & 15) != 0)
         return NF_ERR_LAYOUT;
     InvArgs g;
@@ -449,6 +473,7 @@ static int inverse_rows_impl(const float* blob, int hidden, int n_steps, const i
     g.wf = reinterpret_cast<const float4*>(p);
     g.z = z; g.ldz = z_row_stride; g.x = x; g.ldx = x_row_stride; g.hid = hidden_out; g.ldh = h_row_stride;
     g.partial = workspace; g.B = B; g.H = H; g.HS = HS;
+    g.ctx0 = context_term; g.gate[0] = gate0; g.gate[1] = gate1; g.ldc = context_row_stride;
     g.full_tiles = workspace ? (H + 1) / g.fpt : 0;
     const int64_t grid = (B + IR - 1) / IR;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
@@ -465,8 +490,9 @@ static int inverse_rows_impl(const float* blob, int hidden, int n_steps, const i
 
 extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags,
                                         const float* z, int64_t z_row_stride, float* x, int64_t x_row_stride,
-                                        float* hidden_out, int64_t h_row_stride, float* workspace,
-                                        size_t workspace_bytes, int64_t B, int features, int K, int tails,
+                                        float* hidden_out, int64_t h_row_stride, const float* context_term,
+                                        const float* gate0, const float* gate1, int64_t context_row_stride,
+                                        float* workspace, size_t workspace_bytes, int64_t B, int features, int K, int tails,
                                         double tail_bound, double min_bin_width, double min_bin_height,
                                         double min_derivative, void* stream) {
     if (B < 0 || !nf_made_rqs_inverse_rows_supported(features, hidden, n_steps, K, tails)) return NF_ERR_SHAPE;
@@ -476,7 +502,8 @@ extern "C" int nf_made_rqs_inverse_rows(const float* blob, int hidden, int n_ste
     const int fpt = 256 / c.P, all_tiles = (features + fpt - 1) / fpt;
     if (workspace_bytes < sizeof(float) * (size_t)all_tiles * (size_t)B) return NF_ERR_SCRATCH;
     return inverse_rows_impl(blob, hidden, n_steps, step_flags, z, z_row_stride, x, x_row_stride, hidden_out,
-                             h_row_stride, workspace, B, features, K, c, stream);
+                             h_row_stride, context_term, gate0, gate1, context_row_stride, workspace, B, features, K, c,
+                             stream);
 }
 
 extern "C" int nf_made_affine_inverse_rows_supported(int features, int hidden, int n_steps) {
@@ -486,11 +513,13 @@ extern "C" int nf_made_affine_inverse_rows_supported(int features, int hidden, i
 
 extern "C" int nf_made_affine_inverse_rows(const float* blob, int hidden, int n_steps, const int* step_flags,
                                            const float* z, int64_t z_row_stride, float* x, int64_t x_row_stride,
-                                           float* hidden_out, int64_t h_row_stride, int64_t B, int features,
-                                           void* stream) {
+                                           float* hidden_out, int64_t h_row_stride, const float* context_term,
+                                           const float* gate0, const float* gate1, int64_t context_row_stride,
+                                           int64_t B, int features, void* stream) {
     if (B < 0 || !nf_made_affine_inverse_rows_supported(features, hidden, n_steps)) return NF_ERR_SHAPE;
     RqsConst c = nf_make_rqs_const(1, 1, 1.0, 0.0, 0.0, 0.0, 1.0);
     c.P = 2;                                    // (scale, shift) interleaved per feature
     return inverse_rows_impl(blob, hidden, n_steps, step_flags, z, z_row_stride, x, x_row_stride, hidden_out,
-                             h_row_stride, nullptr, B, features, KT_AFFINE, c, stream);
+                             h_row_stride, context_term, gate0, gate1, context_row_stride, nullptr, B, features,
+                             KT_AFFINE, c, stream);
 }

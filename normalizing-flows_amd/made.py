@@ -380,5 +380,17 @@ class MADE(nn.Module):
         object.__setattr__(self, '_inverse_rows_cache', (key, pack))
         return pack
 
+    def inverse_rows_context(self, context):
+        """What the row-resident inverse kernel needs from a context: (context_layer(context), sigmoid gate of
+        residual block 0, of block 1), or None without a context.  Raises for networks whose context enters any
+        other way."""
+        if context is None:
+            return None
+        if not hasattr(self, 'context_layer') or len(self.blocks) > 2 or \
+                not all(isinstance(b, MaskedResidualBlock) and hasattr(b, 'context_layer') for b in self.blocks):
+            raise NotImplementedError('context given to a MADE built without context_features')
+        gates = [torch.sigmoid(b.context_layer(context)) for b in self.blocks]
+        return (self.context_layer(context),) + tuple(gates) + (None,) * (2 - len(gates))
+
     def forward(self, inputs, context=None):
         return self.final_layer.fused(self.forward_hidden(inputs, context))

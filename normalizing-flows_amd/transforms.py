@@ -164,7 +164,7 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
         net = self.autoregressive_net
         if self._recording(inputs):
             raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
-        pi = net.inverse_rows_pack(None, None) if ROW_RESIDENT_INVERSE and context is None else None
+        pi = net.inverse_rows_pack(None, None) if ROW_RESIDENT_INVERSE else None
         if pi is None:
             return super().inverse(inputs, context)
         D = net.initial_layer.in_features
@@ -176,7 +176,8 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
         for s in range(0, B, CHUNK_ROWS):
             e = min(B, s + CHUNK_ROWS)
             hidden = torch.empty((e - s, H), dtype=inputs.dtype, device=inputs.device)
-            _lib.made_affine_inverse_rows(pi, inputs[s:e], outputs[s:e], hidden)
+            ctx = net.inverse_rows_context(None if context is None else context[s:e])
+            _lib.made_affine_inverse_rows(pi, inputs[s:e], outputs[s:e], hidden, ctx=ctx)
             self._elementwise(inputs[s:e], net.final_layer.fused(hidden), outputs[s:e], logabsdet[s:e], inverse=True)
         return outputs, logabsdet
 
@@ -275,7 +276,7 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         net = self.autoregressive_net
         if self._recording(inputs):
             raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
-        if context is not None or not self._fusable():
+        if not self._fusable() or (context is not None and not (ROW_RESIDENT_INVERSE and net.inverse_rows_pack(self.num_bins, self.tails))):
             return super().inverse(inputs, context)
         D = net.initial_layer.in_features
         _check_2d(inputs, D)
@@ -297,8 +298,9 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
                 z, out = inputs[s:e], outputs[s:e]
                 hidden = torch.empty((e - s, H), dtype=inputs.dtype, device=inputs.device)
                 ws = _lib.fused_workspace(pf, e - s, inputs.device, planes=False)
+                ctx = net.inverse_rows_context(None if context is None else context[s:e])
                 _lib.made_rqs_inverse_rows(pi, z, out, hidden, ws, self.tail_bound, self.min_bin_width,
-                                           self.min_bin_height, self.min_derivative)
+                                           self.min_bin_height, self.min_derivative, ctx=ctx)
                 _lib.made_rqs(hidden, pf, z, self.tail_bound, inverse=True, out=out, logabsdet=logabsdet[s:e],
                               min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                               min_derivative=self.min_derivative, tiles=(t0, pf.tiles - t0), feat_limit=D,
