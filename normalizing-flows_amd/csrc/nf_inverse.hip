@@ -35,7 +35,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x32 __attribute__((ext_vector_type(32)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int IR = 32;            // samples per workgroup
 constexpr int IT = 512;           // threads = hidden units a workgroup can own
@@ -88,7 +87,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
     float* hlT = smem;                              // [HS][IR] final hidden state, unit-major
     float* part = hlT + g.HS * IR;                  // [2][MW][IR][32] per-wave partial parameter tiles, by feature parity
     float* prmb = part + 2 * MW * IR * 32;          // [2][IR][32] bulk parameters, by feature parity
-    float* prm = prmb + 2 * IR * 32;              // [32][PSTR] wave 0's completed parameters
+    float* prm = prmb + 2 * IR * 32;                // [32][PSTR] wave 0's completed parameters
     float* bc = prm + 32 * PSTR;                    // [2][MAXSTEP][IR] activations of the unit just finished, by parity
     float* sh = bc + 2 * MAXSTEP * IR;              // [2][MAXSTEP][IR] exported running sums of the next unit, by parity
 
@@ -282,55 +281,53 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
         // MFMAs run under the other's VALU work instead of both queueing on the same pipe.
         const bool product_first = wave >= 1 && wave <= 3;
         auto product = [&]() {
-        if (wave > 0) {
-        // ---- feature j+2 over the hidden units 0..j-1 (units j, j+1 join as rank-1 terms in wave 0)
-        if (j + 2 <= H) {
-            f32x16 d;
+            // ---- feature j+2 over the hidden units 0..j-1 (units j, j+1 join as rank-1 terms in wave 0)
+            if (wave > 0 && j + 2 <= H) {
+                f32x16 d;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+                for (int i = 0; i < 16; ++i) d[i] = 0.0f;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int S = wave - 1 + MW * i;
-                if (S < NS) {
-                    const float* ap = hlT + (SS * S + 4 * kh) * IR + arow;
-                    const float a0 = ap[0], a1 = ap[IR], a2 = ap[2 * IR], a3 = ap[3 * IR];
-                    // the first NP super-steps' operands came in a round ahead (the latency of these loads is 1500+
-                    // cycles: the weights live in MALL / HBM), the next NQ at the top of this round, the rest follow
-                    // in place NQ super-steps behind their slot's previous user
-                    float4 b;
-                    if (i < NP) {
-                        b = make_float4(rs[4 + 4 * (i % NP)], rs[5 + 4 * (i % NP)], rs[6 + 4 * (i % NP)], rs[7 + 4 * (i % NP)]);
-                    } else {
-                        b = bq[(i - NP) % NQ];
-                        if (i + NQ < NI && S + NQ * MW < NS) bq[(i - NP) % NQ] = g.wf[(fo + S + NQ * MW) * 64 + lane];
-                    }
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.z, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b.w, d, 0, 0, 0);
-                }
-            }
-            float* pt = part + (par * MW + wave - 1) * IR * 32;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
-                pt[r * 32 + arow] = d[i];
-            }
-            if (j + 3 <= H) {                           // next round: feature j+3 over units 0..j
-                const int NS1 = (j + SS) / SS;
-                const int64_t o = first_superstep(j + 3);
-#pragma unroll
-                for (int i = 0; i < NP; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     const int S = wave - 1 + MW * i;
-                    if (S < NS1) {
-                        const float4 n = g.wf[(o + S) * 64 + lane];
-                        rs[4 + 4 * i] = n.x; rs[5 + 4 * i] = n.y; rs[6 + 4 * i] = n.z; rs[7 + 4 * i] = n.w;
+                    if (S < NS) {
+                        const float* ap = hlT + (SS * S + 4 * kh) * IR + arow;
+                        const float a0 = ap[0], a1 = ap[IR], a2 = ap[2 * IR], a3 = ap[3 * IR];
+                        // the first NP super-steps' operands came in a round ahead (the latency of these loads is 1500+
+                        // cycles: the weights live in MALL / HBM), the next NQ at the top of this round, the rest follow
+                        // in place NQ super-steps behind their slot's previous user
+                        float4 b;
+                        if (i < NP) {
+                            b = make_float4(rs[4 + 4 * (i % NP)], rs[5 + 4 * (i % NP)], rs[6 + 4 * (i % NP)], rs[7 + 4 * (i % NP)]);
+                        } else {
+                            b = bq[(i - NP) % NQ];
+                            if (i + NQ < NI && S + NQ * MW < NS) bq[(i - NP) % NQ] = g.wf[(fo + S + NQ * MW) * 64 + lane];
+                        }
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.x, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.y, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.z, d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b.w, d, 0, 0, 0);
+                    }
+                }
+                float* pt = part + (par * MW + wave - 1) * IR * 32;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (i & 3) + 8 * (i >> 2) + 4 * kh;
+                    pt[r * 32 + arow] = d[i];
+                }
+                if (j + 3 <= H) {                           // next round: feature j+3 over units 0..j
+                    const int NS1 = (j + SS) / SS;
+                    const int64_t o = first_superstep(j + 3);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        const int S = wave - 1 + MW * i;
+                        if (S < NS1) {
+                            const float4 n = g.wf[(o + S) * 64 + lane];
+                            rs[4 + 4 * i] = n.x; rs[5 + 4 * i] = n.y; rs[6 + 4 * i] = n.z; rs[7 + 4 * i] = n.w;
+                        }
                     }
                 }
             }
-        }
-        }
-    STAMP(4)
+            STAMP(4)
         };
         auto sums = [&]() {
             // ---- bulk parameters of feature j+1: bias + last round's partial tiles, fixed order; waves 1..4,
@@ -388,7 +385,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                 for (int s = 0; s < NSTEP; ++s) sh[((par ^ 1) * MAXSTEP + s) * IR + (tid & 31)] = ex[s];
             }
         }
-    STAMP(3)
+        STAMP(3)
         if (wave >= 4) product();
         if (wave == 4) sums();
         STAMP(5)
