@@ -332,7 +332,7 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
 #ifdef NF_KO_EPI
             yv = tile[e * P * LDT + hrow]; ld = yv; bin = 0;
 #else
-            rqs_eval<KT, INV, LDT, true>(tile + e * P * LDT + hrow, xs[r * fpt + e], g.c, yv, ld, bin);
+            rqs_eval<KT, INV, LDT, true, false, const float*, false>(tile + e * P * LDT + hrow, xs[r * fpt + e], g.c, yv, ld, bin);
 #endif
             xs[r * fpt + e] = yv;
             lsum += ld;
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
             for (int u = 0; u < NU; ++u) {
                 const int f = min(fb + u * (XT / 64), fv - 1);
                 if (NF_KO_EVAL) { yv[u] = tile[f * P * XLDT + lane]; ld[u] = yv[u]; bin[u] = 0; }
-                else rqs_eval<KT, INV, XLDT, true, true>(tile + f * P * XLDT + lane, xs[r * fpt + f], g.c, yv[u], ld[u], bin[u]);
+                else rqs_eval<KT, INV, XLDT, true, true, const float*, false>(tile + f * P * XLDT + lane, xs[r * fpt + f], g.c, yv[u], ld[u], bin[u]);
             }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {

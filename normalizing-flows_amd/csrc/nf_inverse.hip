@@ -206,7 +206,7 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                     ld = -logf(scale);
                     bin = 0;
                 } else if constexpr (KT == 0) {
-                    rqs_eval<KT, true, PSTR, false, false, lds_ptr>((lds_ptr)(prm + tid), rs[7], g.c, y, ld, bin);
+                    rqs_eval<KT, true, PSTR, false, false, lds_ptr, false>((lds_ptr)(prm + tid), rs[7], g.c, y, ld, bin);
                 }
 #endif
                 if (row_ok) g.x[row * g.ldx + j] = y;

@@ -103,7 +103,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // the identity at the end), so that several evaluations inlined back to back form one basic block the
 // scheduler can interleave.
 // PT: pointer type of the parameters (an explicit LDS address-space pointer keeps a runtime-K caller off flat loads).
-template <int KT, bool INV, int STRIDE = 1, bool BASE2 = false, bool STRAIGHT = false, class PT = const float*>
+// PREDIV false: the caller guarantees pre_div == 1 (the fused kernels fold it into the weights), which removes a
+// multiply and a select per logit.
+template <int KT, bool INV, int STRIDE = 1, bool BASE2 = false, bool STRAIGHT = false, class PT = const float*,
+          bool PREDIV = true>
 __device__ __forceinline__ void rqs_eval(PT p, float x, const RqsConst& a, float& y, float& ld, int& bin) {
     const int K = KT > 0 ? KT : a.K;
     const bool outside = a.tails && !(x >= a.left && x <= a.right);   // linear tails: identity, logdet 0 (NaN too)
@@ -119,7 +122,7 @@ __device__ __forceinline__ void rqs_eval(PT p, float x, const RqsConst& a, float
     const PT uw = p;
     const PT uh = p + K * STRIDE;
     const PT ud = p + 2 * K * STRIDE;
-    const bool scaled = a.pre_div != 1.0f;
+    const bool scaled = PREDIV && a.pre_div != 1.0f;
 
     // softmax denominators: max, then sum of exp(u - max) left to right
     auto raw = [&](PT u, int k) {
