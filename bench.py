@@ -211,7 +211,7 @@ def main():
                                     'unit': 'GB/s', 'frac': byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                     'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': byts}
         out['kernel_ms'] = {'%s_%dx%d_rows%d' % (k[0], k[1], k[2], k[3]): round(v[1], 4) for k, v in kern.items()}
-        if not args.no_bf16 and not args.stream_total:
+        if not args.no_bf16 and not args.stream_total and world == 1:       # (secondary legs: single-GPU runs only)
             # secondary figures: the same step in the other matrix modes (this rank's shard)
             out['other_modes'] = {}
             for mode in ('f32', 'bf16x3', 'f16x2', 'bf16'):
@@ -250,7 +250,7 @@ def main():
         out['measured_device_peaks'] = {'mfma_f32_tflops': f32_tf, 'mfma_bf16_tflops': bf16_tf, 'copy_gbs': copy_gbs,
                                         'note': 'back-to-back MFMA issue loop / 1 GiB float4 copy on this device; the '
                                                 'roofline fractions above use the nominal peaks'}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
             n = min(args.cpu_sample, B)
             v, cores, err = cpu_baseline(sd_cpu, x[:n].cpu(), logp[:n].cpu(), reps=3)
             out['cpu_baseline'] = {'value': v, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
