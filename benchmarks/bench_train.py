@@ -24,6 +24,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--layers', type=int, default=5)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16x2', 'bf16x3'],
+                    help='matrix mode of the forward and input-gradient GEMMs (weight gradients: fp32 MFMA)')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -34,6 +36,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     D, H, K = 784, 512, 8
+    nf.set_matmul_dtype(args.dtype)
     torch.manual_seed(0)
     layers = [nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, num_bins=K, tails='linear', tail_bound=3.)
               for _ in range(args.layers)]
@@ -66,7 +69,7 @@ def main():
     if rank == 0:
         print(json.dumps({'metric': 'training samples/sec (fwd+bwd+allreduce+Adam), RQ-spline MAF D=784',
                           'value': world * args.batch * args.steps / dt, 'unit': 'samples/s', 'n_gpus': world,
-                          'ms_per_step': 1e3 * dt / args.steps, 'batch_per_gpu': args.batch, 'dtype': 'f32',
+                          'ms_per_step': 1e3 * dt / args.steps, 'batch_per_gpu': args.batch, 'dtype': args.dtype,
                           'losses': losses, 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30}))
     if dist is not None:
         dist.destroy_process_group()

@@ -210,6 +210,10 @@ int nf_linear_split_tiles(int out);
 size_t nf_linear_split_packed_bytes(int out, int in, int dtype);
 int nf_linear_split_pack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
                          void* packed, int32_t* ktab, float* bias_packed, void* stream);
+/* The same after a weight update with an unchanged mask: packed / bias_packed / the operand scale in ktab are
+ * rewritten, the K-range table in ktab (a scan of the whole mask) is kept.  Training repacks every step. */
+int nf_linear_split_repack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
+                         void* packed, int32_t* ktab, float* bias_packed, void* stream);
 /* slot <- bit pattern of the largest finite |x[b, c]| (cols % 4 == 0, 16-byte aligned rows). */
 int nf_maxabs(const float* x, int64_t x_row_stride, int64_t B, int cols, uint32_t* slot, void* stream);
 /* y = [relu](x) @ (W*mask)^T + bias (+ residual) [relu].  x_max: slot holding max |x| (nf_maxabs, or the y_max of

@@ -86,6 +86,8 @@ _SIGNATURES = {
     'nf_linear_split_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_linear_split_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'nf_linear_split_repack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                          _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'nf_maxabs': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p]),
     'nf_masked_linear_split_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                               _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
@@ -219,21 +221,28 @@ class PackedLinearSplit:
     """Device buffers of nf_linear_split_pack: one [out,in] layer as fp16 / bf16 term planes in 256-row tiles."""
     __slots__ = ('out', 'inp', 'dtype', 'packed', 'ktab', 'bias', 'tiles')
 
-    def __init__(self, weight, mask, bias, dtype):
+    def __init__(self, weight, mask, bias, dtype, reuse=None):
+        """reuse: the previous pack of the same layer with the same mask - its buffers and K-range table are kept
+        (nf_linear_split_repack), only the weights, bias and operand scale are rewritten."""
         lib = load()
         w = _dev(weight.detach().contiguous(), 'weight')
         m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
         b = None if bias is None else _dev(bias.detach().contiguous(), 'bias')
         self.out, self.inp, self.dtype = int(w.shape[0]), int(w.shape[1]), dtype
         self.tiles = lib.nf_linear_split_tiles(self.out)
-        self.packed = torch.empty(lib.nf_linear_split_packed_bytes(self.out, self.inp, dtype), dtype=torch.uint8,
-                                  device=w.device)
-        self.ktab = torch.zeros(2 * self.tiles + 2, dtype=torch.int32, device=w.device)
-        self.bias = torch.empty(256 * self.tiles, dtype=torch.float32, device=w.device)
+        fresh = reuse is None or (reuse.out, reuse.inp, reuse.dtype) != (self.out, self.inp, dtype) \
+            or reuse.packed.device != w.device
+        if fresh:
+            self.packed = torch.empty(lib.nf_linear_split_packed_bytes(self.out, self.inp, dtype), dtype=torch.uint8,
+                                      device=w.device)
+            self.ktab = torch.zeros(2 * self.tiles + 2, dtype=torch.int32, device=w.device)
+            self.bias = torch.empty(256 * self.tiles, dtype=torch.float32, device=w.device)
+        else:
+            self.packed, self.ktab, self.bias = reuse.packed, reuse.ktab, reuse.bias
+        fn = lib.nf_linear_split_pack if fresh else lib.nf_linear_split_repack
         with torch.cuda.device(w.device):
-            _check(lib.nf_linear_split_pack(w.data_ptr(), _ptr(m), _ptr(b), self.out, self.inp, dtype,
-                                            self.packed.data_ptr(), self.ktab.data_ptr(), self.bias.data_ptr(),
-                                            _stream()), 'nf_linear_split_pack')
+            _check(fn(w.data_ptr(), _ptr(m), _ptr(b), self.out, self.inp, dtype, self.packed.data_ptr(),
+                      self.ktab.data_ptr(), self.bias.data_ptr(), _stream()), 'nf_linear_split_pack')
 
 
 def split_gemm_supported(x, in_features):

@@ -15,11 +15,20 @@ import torch
 from . import _lib
 
 
+def _split_mode(x, width):
+    """True when the matrix mode is one of the split-operand ones (fp32 contract on the fp16 / bf16 matrix pipe)
+    and the split GEMM kernel takes this operand; then forward and input-gradient GEMMs run on it too."""
+    from . import made
+    return made.get_matmul_dtype() in made._SPLIT_MODES and _lib.split_gemm_supported(x, width)
+
+
 class MaskedLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, layer, relu_in):
-        pl = layer._packed_linear()
-        y = _lib.masked_linear(x, pl, residual=residual, relu_in=relu_in)
+        if _split_mode(x, layer.in_features):
+            y = _lib.masked_linear_split(x, layer._packed_linear_split(), residual=residual, relu_in=relu_in)
+        else:
+            y = _lib.masked_linear(x, layer._packed_linear(), residual=residual, relu_in=relu_in)
         ctx.save_for_backward(x)
         ctx.layer = layer
         ctx.relu_in = relu_in
@@ -34,7 +43,13 @@ class MaskedLinearFn(torch.autograd.Function):
         grad_y = grad_y.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if ctx.relu_in else None)
+            if _split_mode(grad_y, layer.out_features):
+                # dX = dY @ (W * mask): the same split-operand kernel on the transposed layer, ReLU gate after it
+                gx = _lib.masked_linear_split(grad_y, layer._packed_linear_split_t())
+                if ctx.relu_in:
+                    gx.mul_(x > 0)
+            else:
+                gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if ctx.relu_in else None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = _lib.masked_linear_bwd_weight(x, grad_y, getattr(layer, 'mask', None), layer._packed_linear().ktab,
                                                    ctx.relu_in, want_bias=ctx.has_bias)

@@ -1219,8 +1219,8 @@ extern "C" size_t nf_linear_split_packed_bytes(int out, int in, int dtype) {
     return (size_t)nf_linear_split_tiles(out) * FN * kpad_of(in) * 2 * split_terms(dtype);
 }
 
-extern "C" int nf_linear_split_pack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
-                                    void* packed, int32_t* ktab, float* bias_packed, void* stream) {
+static int linear_split_pack_impl(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
+                                  void* packed, int32_t* ktab, float* bias_packed, bool table, void* stream) {
     if (!W || !packed || !ktab || !bias_packed) return NF_ERR_NULL;
     if (out <= 0 || in <= 0) return NF_ERR_SHAPE;
     if (!split_terms(dtype)) return NF_ERR_DTYPE;
@@ -1241,8 +1241,18 @@ extern "C" int nf_linear_split_pack(const float* W, const float* mask, const flo
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x3>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
                            kpad, total, 1, 0, 1.0f, (const unsigned*)nullptr, (__bf16*)packed, bias_packed);
     }
-    hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, FN, ktab);
+    if (table) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, FN, ktab);
     return nf_launch_status();
+}
+
+extern "C" int nf_linear_split_pack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
+                                    void* packed, int32_t* ktab, float* bias_packed, void* stream) {
+    return linear_split_pack_impl(W, mask, bias, out, in, dtype, packed, ktab, bias_packed, true, stream);
+}
+
+extern "C" int nf_linear_split_repack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
+                                      void* packed, int32_t* ktab, float* bias_packed, void* stream) {
+    return linear_split_pack_impl(W, mask, bias, out, in, dtype, packed, ktab, bias_packed, false, stream);
 }
 
 extern "C" int nf_maxabs(const float* x, int64_t x_row_stride, int64_t B, int cols, uint32_t* slot, void* stream) {

@@ -87,9 +87,26 @@ class _PackedMixin:
                get_matmul_dtype(), self.weight.device, None if mask is None else (mask._version, mask.data_ptr()))
         cached = getattr(self, '_split_cache', None)
         if cached is None or cached[0] != key:
-            pls = _lib.PackedLinearSplit(self.weight, mask, self.bias, _MATMUL_DTYPE[get_matmul_dtype()])
+            same_mask = cached is not None and cached[0][-1] == key[-1]       # then the K-range table is still valid
+            pls = _lib.PackedLinearSplit(self.weight, mask, self.bias, _MATMUL_DTYPE[get_matmul_dtype()],
+                                         reuse=cached[1] if same_mask else None)
             object.__setattr__(self, '_split_cache', (key, pls))
             cached = self._split_cache
+        return cached[1]
+
+    def _packed_linear_split_t(self):
+        """Term-plane pack of the transposed layer (input-gradient GEMM in the split-operand modes), cached likewise."""
+        mask = getattr(self, 'mask', None)
+        key = (self.weight._version, self.weight.data_ptr(), get_matmul_dtype(), self.weight.device,
+               None if mask is None else (mask._version, mask.data_ptr()))
+        cached = getattr(self, '_split_t_cache', None)
+        if cached is None or cached[0] != key:
+            same_mask = cached is not None and cached[0][-1] == key[-1]
+            pls = _lib.PackedLinearSplit(self.weight.detach().t().contiguous(),
+                                         None if mask is None else mask.t().contiguous(), None,
+                                         _MATMUL_DTYPE[get_matmul_dtype()], reuse=cached[1] if same_mask else None)
+            object.__setattr__(self, '_split_t_cache', (key, pls))
+            cached = self._split_t_cache
         return cached[1]
 
     def _packed_fused_final(self, features, num_bins, tails, logit_div=1.0):

@@ -796,6 +796,18 @@ def test_training_gradients_match_autograd_of_the_oracle(nf, D, H, K, B):
             assert ((got - ref).abs().max().item() / scale) < 2e-3, (k, (got - ref).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16x3'])
+def test_training_gradients_in_split_operand_modes(nf, mode):
+    """The same gradient check with the forward and input-gradient GEMMs on the split-operand kernel (weight
+    gradients stay on fp32 MFMA): the fp32 bars hold."""
+    nf.set_matmul_dtype(mode)
+    try:
+        test_training_gradients_match_autograd_of_the_oracle(nf, 40, 136, 4, 130)
+        test_training_gradients_match_autograd_of_the_oracle(nf, 16, 32, 8, 96)
+    finally:
+        nf.set_matmul_dtype('f32')
+
+
 def test_short_training_run_lowers_the_loss(nf):
     """A few Adam steps on a 2-D-correlated Gaussian: the loss goes down and weights move only where unmasked."""
     torch.manual_seed(0)
