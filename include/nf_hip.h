@@ -284,6 +284,19 @@ int nf_made_affine_inverse_rows(const float* blob, int hidden, int n_steps, cons
                                 int64_t h_row_stride, const float* context_term, const float* gate0, const float* gate1,
                                 int64_t context_row_stride, int64_t B, int features, void* stream);
 
+/* The same for the MaskedPiecewise{Linear,Quadratic,Cubic}AutoregressiveTransform classes (transforms.py:568-769,
+ * splines/linear.py, quadratic.py, cubic.py): family 1 = linear (P = K parameters per feature), 2 = quadratic
+ * (P = 2K+1, or 2K-1 with linear tails), 3 = cubic (P = 2K+2 on [-tail_bound, tail_bound], widths / heights divided
+ * by pre_div); P <= 32.  As with the affine variant the caller finishes with the final layer on hidden_out and one
+ * nf_{linear,quadratic,cubic}_spline_fwd(inverse = 1) over all features. */
+int nf_made_family_inverse_rows_supported(int family, int features, int hidden, int n_steps, int K, int tails);
+int nf_made_family_inverse_rows(int family, const float* blob, int hidden, int n_steps, const int* step_flags,
+                                const float* z, int64_t z_row_stride, float* x, int64_t x_row_stride,
+                                float* hidden_out, int64_t h_row_stride, const float* context_term, const float* gate0,
+                                const float* gate1, int64_t context_row_stride, int64_t B, int features, int K,
+                                int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                                double pre_div, void* stream);
+
 /* ---- affine transform (replaces transforms.py:328-347 coupling, :540-566 autoregressive) -------- */
 
 /* scale = sigmoid(u + 2) + 1e-3; forward y = scale*x + shift, inverse y = (x - shift)/scale;

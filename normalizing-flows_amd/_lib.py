@@ -107,6 +107,12 @@ _SIGNATURES = {
     'nf_made_affine_inverse_rows': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                                _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
                                                _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p]),
+    'nf_made_family_inverse_rows_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'nf_made_family_inverse_rows': (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                               _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                                               _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
+                                               _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double,
+                                               _c.c_void_p]),
     'nf_made_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -472,21 +478,43 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
     return out, logabsdet, bins
 
 
+FAMILY_CODE = {'linear': 1, 'quadratic': 2, 'cubic': 3}
+
+
+def inverse_params_per_feature(kind, num_bins, tails):
+    t = tails == 'linear'
+    return {'rq': 3 * num_bins - 1 if t else 3 * num_bins + 1, 'affine': 2, 'linear': num_bins,
+            'quadratic': 2 * num_bins - 1 if t else 2 * num_bins + 1, 'cubic': 2 * num_bins + 2}[kind]
+
+
+def inverse_rows_supported(kind, features, hidden, n_steps, num_bins, tails):
+    """Does the row-resident inverse kernel take this network / elementwise transform?"""
+    lib = load()
+    t = 1 if tails == 'linear' else 0
+    if tails not in (None, 'linear'):
+        return False
+    if kind == 'rq':
+        return lib.nf_made_rqs_inverse_rows_supported(int(features), int(hidden), int(n_steps), int(num_bins), t) == 1
+    if kind == 'affine':
+        return lib.nf_made_affine_inverse_rows_supported(int(features), int(hidden), int(n_steps)) == 1
+    return lib.nf_made_family_inverse_rows_supported(FAMILY_CODE[kind], int(features), int(hidden), int(n_steps),
+                                                     int(num_bins), t) == 1
+
+
 class PackedInverse:
     """Parameter blob of nf_made_rqs_inverse_rows (layout: include/nf_hip.h) for a MADE whose hidden units are in
     degree order.  `steps` = [(weight, mask, bias, flags, (bn_scale, bn_shift) or None)] of the hidden stack, then
     the final layer."""
     __slots__ = ('hidden', 'features', 'P', 'K', 'tails', 'n_steps', 'flags', 'blob')
 
-    def __init__(self, steps, final_weight, final_mask, final_bias, features, num_bins, tails):
-        """num_bins None: the affine transform (2 parameters per feature)."""
+    def __init__(self, steps, final_weight, final_mask, final_bias, features, num_bins, tails, kind='rq'):
+        """kind: 'rq' (3K-1 / 3K+1 parameters per feature), 'affine' (2), 'linear' (K), 'quadratic' (2K-1 / 2K+1),
+        'cubic' (2K+2)."""
         lib = load()
         H = int(final_weight.shape[1])
         t = 1 if tails == 'linear' else 0
-        if num_bins is None:
-            P, num_bins = 2, 0
-        else:
-            P = 3 * num_bins - 1 if t else 3 * num_bins + 1
+        num_bins = 0 if num_bins is None else int(num_bins)
+        P = inverse_params_per_feature(kind, num_bins, tails)
         HS = (H + 63) // 64 * 64
         dev = final_weight.device
         parts, flags = [], []
@@ -595,6 +623,32 @@ def made_affine_inverse_rows(pi, z, out, hidden, ctx=None):
     with torch.cuda.device(z.device):
         code = launch() if _timer is None else _timer.record(('made_affine_inverse_rows', pi.hidden, pi.features, B), launch)
         _check(code, 'nf_made_affine_inverse_rows')
+
+
+def made_family_inverse_rows(pi, kind, z, out, hidden, tail_bound=1.0, min_bin_width=1e-3, min_bin_height=1e-3,
+                             pre_div=1.0, ctx=None):
+    """Features 0..H of the autoregressive inverse of a linear / quadratic / cubic spline transform and the final
+    hidden state (nf_made_family_inverse_rows)."""
+    lib = load()
+    _dev(z, 'inputs')
+    _dev(out, 'outputs')
+    _dev(hidden, 'hidden')
+    B = z.shape[0]
+    zp, zs = _rows(z, 'inputs')
+    xp, xs = _rows(out, 'outputs')
+    hp, hs = _rows(hidden, 'hidden')
+    if z.shape[1] != pi.features or out.shape != z.shape or hidden.shape != (B, pi.hidden):
+        raise ValueError('Expected inputs / outputs [B,%d] and hidden [B,%d]' % (pi.features, pi.hidden))
+    c0, g0, g1, cs = _context_args(ctx, B, pi.hidden)
+
+    def launch():
+        return lib.nf_made_family_inverse_rows(FAMILY_CODE[kind], pi.blob.data_ptr(), pi.hidden, pi.n_steps, pi.flags,
+                                               zp, zs, xp, xs, hp, hs, c0, g0, g1, cs, B, pi.features, pi.K, pi.tails,
+                                               float(tail_bound), float(min_bin_width), float(min_bin_height),
+                                               float(pre_div), _stream())
+    with torch.cuda.device(z.device):
+        code = launch() if _timer is None else _timer.record(('made_family_inverse_rows', pi.hidden, pi.features, B), launch)
+        _check(code, 'nf_made_family_inverse_rows')
 
 
 def made_rqs_inverse_rows(pi, z, out, hidden, workspace, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,

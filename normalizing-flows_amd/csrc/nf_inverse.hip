@@ -30,6 +30,7 @@
 // in transforms.py: one 128/256-column tile per layer per feature, ~10-100 x more MACs than needed).
 #include "nf_common.h"
 #include "nf_rqs_eval.h"
+#include "nf_spline_families.h"
 
 namespace {
 
@@ -48,7 +49,9 @@ constexpr int MW = IW - 1;        // waves on the final-layer product (wave 0 in
 constexpr int NI = (IT / SS + MW - 1) / MW;   // super-steps per wave at most
 
 constexpr int F_RELU_IN = 1, F_RESIDUAL = 2, F_RELU_OUT = 4;
-constexpr int KT_AFFINE = -1;     // elementwise transform: affine (2 parameters per feature) instead of the spline
+// elementwise transform instead of the RQ spline (KT >= 0: its bin count, 0 = runtime): affine (2 parameters per
+// feature), linear / quadratic / cubic spline (nf_spline_families.h)
+constexpr int KT_AFFINE = -1, KT_LINEAR = -2, KT_QUADRATIC = -3, KT_CUBIC = -4;
 
 // First super-step of feature f in the triangular final-layer pack: sum over g < f of ceil(g / 8)
 __host__ __device__ inline int first_superstep(int f) {
@@ -177,9 +180,15 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
 #pragma unroll
                 for (int i = 0; i < 16; ++i) c[i] = pb[((i & 3) + 8 * (i >> 2)) * 32];
                 c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rs[9], c, 0, 0, 0);
-                float* po = prm + arow * PSTR + 4 * kh;
+                if constexpr (KT <= KT_LINEAR) {        // [sample][parameter]: the family evaluators read unit stride
+                    float* po = prm + 4 * kh * PSTR + arow;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) po[(i & 3) + 8 * (i >> 2)] = c[i];
+                    for (int i = 0; i < 16; ++i) po[((i & 3) + 8 * (i >> 2)) * PSTR] = c[i];
+                } else {                                // [parameter][sample]
+                    float* po = prm + arow * PSTR + 4 * kh;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) po[(i & 3) + 8 * (i >> 2)] = c[i];
+                }
                 rs[9] = g.wl[(int64_t)(j < H ? j + 1 : H) * 64 + lane];      // next round's weight rows
             }
             STAMP(0)
@@ -207,6 +216,12 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
                     bin = 0;
                 } else if constexpr (KT == 0) {
                     rqs_eval<KT, true, PSTR, false, false, lds_ptr, false>((lds_ptr)(prm + tid), rs[7], g.c, y, ld, bin);
+                } else if constexpr (KT == KT_LINEAR) {
+                    lin_eval<true, lds_ptr>((lds_ptr)(prm + tid * PSTR), rs[7], g.c, y, ld, bin);
+                } else if constexpr (KT == KT_QUADRATIC) {
+                    quad_eval<true, lds_ptr>((lds_ptr)(prm + tid * PSTR), rs[7], g.c, y, ld, bin);
+                } else if constexpr (KT == KT_CUBIC) {
+                    cubic_eval<true, lds_ptr>((lds_ptr)(prm + tid * PSTR), rs[7], g.c, y, ld, bin);
                 }
 #endif
                 if (row_ok) g.x[row * g.ldx + j] = y;
@@ -421,6 +436,9 @@ int launch_steps(const InvArgs& g, int K, unsigned grid, size_t lds, hipStream_t
         return nf_launch_status();
     };
     if (K == KT_AFFINE) return go(made_rqs_inverse_kernel<NSTEP, KT_AFFINE>);
+    if (K == KT_LINEAR) return go(made_rqs_inverse_kernel<NSTEP, KT_LINEAR>);
+    if (K == KT_QUADRATIC) return go(made_rqs_inverse_kernel<NSTEP, KT_QUADRATIC>);
+    if (K == KT_CUBIC) return go(made_rqs_inverse_kernel<NSTEP, KT_CUBIC>);
     return K == 8 ? go(made_rqs_inverse_kernel<NSTEP, 8>) : go(made_rqs_inverse_kernel<NSTEP, 0>);
 }
 
@@ -519,4 +537,43 @@ extern "C" int nf_made_affine_inverse_rows(const float* blob, int hidden, int n_
     return inverse_rows_impl(blob, hidden, n_steps, step_flags, z, z_row_stride, x, x_row_stride, hidden_out,
                              h_row_stride, context_term, gate0, gate1, context_row_stride, nullptr, B, features,
                              KT_AFFINE, c, stream);
+}
+
+// family: 1 linear (P = K), 2 quadratic (P = 2K+1, or 2K-1 with linear tails), 3 cubic (P = 2K+2, on [-bound, bound])
+static int family_params(int family, int K, int tails) {
+    if (K < 1) return 0;
+    switch (family) {
+        case 1: return K;
+        case 2: return K < 2 ? 0 : (tails ? 2 * K - 1 : 2 * K + 1);
+        case 3: return 2 * K + 2;
+    }
+    return 0;
+}
+
+extern "C" int nf_made_family_inverse_rows_supported(int family, int features, int hidden, int n_steps, int K, int tails) {
+    const int P = family_params(family, K, tails);
+    return P >= 1 && P <= 32 && nf_made_affine_inverse_rows_supported(features, hidden, n_steps) ? 1 : 0;
+}
+
+extern "C" int nf_made_family_inverse_rows(int family, const float* blob, int hidden, int n_steps, const int* step_flags,
+                                           const float* z, int64_t z_row_stride, float* x, int64_t x_row_stride,
+                                           float* hidden_out, int64_t h_row_stride, const float* context_term,
+                                           const float* gate0, const float* gate1, int64_t context_row_stride,
+                                           int64_t B, int features, int K, int tails, double tail_bound,
+                                           double min_bin_width, double min_bin_height, double pre_div, void* stream) {
+    if (B < 0 || !nf_made_family_inverse_rows_supported(family, features, hidden, n_steps, K, tails) || !(pre_div > 0.0))
+        return NF_ERR_SHAPE;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+    // the constants of the standalone family kernels (nf_spline.hip, family_fwd)
+    RqsConst c = nf_make_rqs_const(K, tails, tail_bound, family == 1 ? 0.0 : min_bin_width,
+                                   family == 1 ? 0.0 : min_bin_height, 1e-3, family == 3 ? pre_div : 1.0);
+    c.P = family_params(family, K, tails);
+    if (family == 3) {
+        c.left = (float)-tail_bound;
+        c.right = (float)tail_bound;
+        c.span = (float)(2.0 * tail_bound);
+    }
+    return inverse_rows_impl(blob, hidden, n_steps, step_flags, z, z_row_stride, x, x_row_stride, hidden_out,
+                             h_row_stride, context_term, gate0, gate1, context_row_stride, nullptr, B, features,
+                             family == 1 ? KT_LINEAR : family == 2 ? KT_QUADRATIC : KT_CUBIC, c, stream);
 }

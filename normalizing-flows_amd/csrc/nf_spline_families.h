@@ -13,8 +13,8 @@ __device__ __forceinline__ float nf_linspace01(int i, int K) {
 }
 
 // Linear spline: p[0..K) = unnormalised pdf of K equal bins (linear.py:35-94; tails :9-33).
-template <bool INV>
-__device__ __forceinline__ void lin_eval(const float* __restrict__ p, float x, const RqsConst& a, float& y, float& ld,
+template <bool INV, class PT = const float*>
+__device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                          int& bin) {
     const int K = a.K;
     if (a.tails && !(x >= a.left && x <= a.right)) {
@@ -75,8 +75,8 @@ __device__ __forceinline__ void lin_eval(const float* __restrict__ p, float x, c
 // Quadratic spline: p[0..K) unnormalised widths, p[K..P) unnormalised heights of the piecewise-linear density
 // (K+1 knots; with linear tails only the K-1 interior ones, the boundary pair set so that it normalises to 1)
 // (quadratic.py:48-135; tails :11-46).
-template <bool INV>
-__device__ __forceinline__ void quad_eval(const float* __restrict__ p, float x, const RqsConst& a, float& y, float& ld,
+template <bool INV, class PT = const float*>
+__device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                           int& bin) {
     const int K = a.K;
     if (a.tails && !(x >= a.left && x <= a.right)) {
@@ -85,8 +85,8 @@ __device__ __forceinline__ void quad_eval(const float* __restrict__ p, float x, 
         bin = -1;
         return;
     }
-    const float* uw = p;
-    const float* uh = p + K;
+    const PT uw = p;
+    const PT uh = p + K;
     const float t = (x - a.left) / a.span;
     float m = -INFINITY;
     for (int k = 0; k < K; ++k) m = fmaxf(m, uw[k]);
@@ -155,8 +155,8 @@ __device__ __forceinline__ void quad_eval(const float* __restrict__ p, float x, 
 // p[2K], p[2K+1] unnormalised left / right boundary derivatives.  The interval is [a.left, a.right] in both
 // directions (the reference's default is [-10, 10]); a.pre_div divides the width / height logits (coupling).
 // eps and the near-quadratic threshold are the reference's defaults (1e-5, 1e-3).
-template <bool INV>
-__device__ __forceinline__ void cubic_eval(const float* __restrict__ p, float x, const RqsConst& a, float& y, float& ld,
+template <bool INV, class PT = const float*>
+__device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                            int& bin) {
     const int K = a.K;
     if (a.tails && !(x >= a.left && x <= a.right)) {
@@ -165,10 +165,10 @@ __device__ __forceinline__ void cubic_eval(const float* __restrict__ p, float x,
         bin = -1;
         return;
     }
-    const float* uw = p;
-    const float* uh = p + K;
+    const PT uw = p;
+    const PT uh = p + K;
     const bool scaled = a.pre_div != 1.0f;
-    auto raw = [&](const float* u, int k) { return scaled ? u[k] / a.pre_div : u[k]; };
+    auto raw = [&](PT u, int k) { return scaled ? u[k] / a.pre_div : u[k]; };
     const float t = (x - a.left) / a.span;
     float mw = -INFINITY, mh = -INFINITY;
     for (int k = 0; k < K; ++k) {

@@ -361,14 +361,15 @@ class MADE(nn.Module):
                         relu_in=relu_in, relu_out=relu_out, out=bufs[dst], tiles=tiles)
         return bufs[last]
 
-    def inverse_rows_pack(self, num_bins, tails):
+    def inverse_rows_pack(self, num_bins, tails, kind=None):
         """Parameter blob for the row-resident inverse kernel (nf_made_rqs_inverse_rows; num_bins None: the affine
         variant nf_made_affine_inverse_rows), or None when this
         network is outside its scope: hidden units must be in degree order in every layer (the non-random masks
         with hidden_features <= features - 1), BatchNorm in eval mode only, the step structure of hidden_program()."""
+        kind = kind or ('affine' if num_bins is None else 'rq')
         steps, _ = self.hidden_program()
         layers = [st[0] for st in steps] + [self.final_layer]
-        key = tuple((l.weight._version, l.weight.data_ptr(), None if l.bias is None else l.bias._version,
+        key = (kind,) + tuple((l.weight._version, l.weight.data_ptr(), None if l.bias is None else l.bias._version,
                      l.mask._version) for l in layers) + (self.final_layer.weight.device, num_bins, tails)
         for st in steps:
             if st[6] is not None:
@@ -380,8 +381,7 @@ class MADE(nn.Module):
             return cached[1]
         D, H = self.initial_layer.in_features, self.final_layer.in_features
         pack = None
-        ok = (_lib.made_affine_inverse_rows_supported(D, H, len(steps)) if num_bins is None
-              else _lib.made_rqs_inverse_rows_supported(D, H, len(steps), num_bins, tails))
+        ok = _lib.inverse_rows_supported(kind, D, H, len(steps), num_bins or 0, tails)
         flags = []
         want = torch.arange(1, H + 1)
         for i, (layer, src, dst, res, relu_in, relu_out, bn) in enumerate(steps):
@@ -393,7 +393,7 @@ class MADE(nn.Module):
                                         None if st[6] is None else _bn_scale_shift(st[6]))
                                        for st, fl in zip(steps, flags)],
                                       self.final_layer.weight, self.final_layer.mask, self.final_layer.bias, D,
-                                      num_bins, tails)
+                                      num_bins, tails, kind=kind)
         object.__setattr__(self, '_inverse_rows_cache', (key, pack))
         return pack
 

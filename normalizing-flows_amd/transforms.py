@@ -124,6 +124,31 @@ class AutoregressiveTransform(nn.Module):
                 outputs[s:e].copy_(cur)
         return outputs, logabsdet
 
+    def _inverse_via_rows(self, inputs, context, kind, num_bins, tails, rows_kernel):
+        """Same result as the D full passes above.  With hidden units in degree order one launch carries 32 samples
+        per workgroup through features 0..H (nf_inverse.hip, see the RQ-spline transform below); these elementwise
+        inverses depend on earlier features only through the parameters, so the final hidden state that launch leaves
+        behind gives every feature and logabsdet in one final-layer GEMM + one elementwise pass."""
+        net = self.autoregressive_net
+        if self._recording(inputs):
+            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
+        pi = net.inverse_rows_pack(num_bins, tails, kind=kind) if ROW_RESIDENT_INVERSE else None
+        if pi is None:
+            return AutoregressiveTransform.inverse(self, inputs, context)
+        D = net.initial_layer.in_features
+        _check_2d(inputs, D)
+        made_module._require_inference(net.final_layer)
+        B, H = inputs.shape[0], net.final_layer.in_features
+        outputs = torch.zeros_like(inputs)
+        logabsdet = torch.zeros(B, dtype=inputs.dtype, device=inputs.device)
+        for s in range(0, B, CHUNK_ROWS):
+            e = min(B, s + CHUNK_ROWS)
+            hidden = torch.empty((e - s, H), dtype=inputs.dtype, device=inputs.device)
+            ctx = net.inverse_rows_context(None if context is None else context[s:e])
+            rows_kernel(pi, inputs[s:e], outputs[s:e], hidden, ctx)
+            self._elementwise(inputs[s:e], net.final_layer.fused(hidden), outputs[s:e], logabsdet[s:e], inverse=True)
+        return outputs, logabsdet
+
     def _transform_rows(self, net_inputs, inputs, context, outputs, logabsdet, inverse):
         """Conditioner on `net_inputs`, elementwise transform of `inputs` into outputs / logabsdet."""
         params = self.autoregressive_net(net_inputs, context)
@@ -157,29 +182,8 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
         _lib.affine(inputs, params, _lib.NF_AFFINE_INTERLEAVED, inverse=inverse, out=outputs, logabsdet=logabsdet)
 
     def inverse(self, inputs, context=None):
-        """Same result as the reference's D full passes (transforms.py:493-500).  With hidden units in degree
-        order one launch carries 32 samples per workgroup through features 0..H (nf_inverse.hip, see the spline
-        transform below); x = (z - shift) / scale is elementwise in z once the parameters are known, so the final
-        hidden state that launch leaves behind gives every feature and logabsdet in one GEMM + one affine pass."""
-        net = self.autoregressive_net
-        if self._recording(inputs):
-            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
-        pi = net.inverse_rows_pack(None, None) if ROW_RESIDENT_INVERSE else None
-        if pi is None:
-            return super().inverse(inputs, context)
-        D = net.initial_layer.in_features
-        _check_2d(inputs, D)
-        made_module._require_inference(net.final_layer)
-        B, H = inputs.shape[0], net.final_layer.in_features
-        outputs = torch.zeros_like(inputs)
-        logabsdet = torch.zeros(B, dtype=inputs.dtype, device=inputs.device)
-        for s in range(0, B, CHUNK_ROWS):
-            e = min(B, s + CHUNK_ROWS)
-            hidden = torch.empty((e - s, H), dtype=inputs.dtype, device=inputs.device)
-            ctx = net.inverse_rows_context(None if context is None else context[s:e])
-            _lib.made_affine_inverse_rows(pi, inputs[s:e], outputs[s:e], hidden, ctx=ctx)
-            self._elementwise(inputs[s:e], net.final_layer.fused(hidden), outputs[s:e], logabsdet[s:e], inverse=True)
-        return outputs, logabsdet
+        return self._inverse_via_rows(inputs, context, 'affine', None, None,
+                                      lambda pi, z, out, hid, ctx: _lib.made_affine_inverse_rows(pi, z, out, hid, ctx=ctx))
 
 
 class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTransform):
@@ -352,6 +356,11 @@ class MaskedPiecewiseLinearAutoregressiveTransform(AutoregressiveTransform):
         _lib.linear_spline(inputs, params, self.num_bins, tails=None, inverse=inverse, out=outputs,
                            logabsdet=logabsdet)
 
+    def inverse(self, inputs, context=None):
+        return self._inverse_via_rows(inputs, context, 'linear', self.num_bins, None,
+                                      lambda pi, z, out, hid, ctx: _lib.made_family_inverse_rows(
+                                          pi, 'linear', z, out, hid, ctx=ctx))
+
 
 class MaskedPiecewiseQuadraticAutoregressiveTransform(AutoregressiveTransform):
     """Piecewise-quadratic CDF spline with MADE-produced widths / knot heights (reference transforms.py:618-705;
@@ -390,6 +399,12 @@ class MaskedPiecewiseQuadraticAutoregressiveTransform(AutoregressiveTransform):
                               inverse=inverse, out=outputs, logabsdet=logabsdet, min_bin_width=self.min_bin_width,
                               min_bin_height=self.min_bin_height)
 
+    def inverse(self, inputs, context=None):
+        return self._inverse_via_rows(inputs, context, 'quadratic', self.num_bins, self.tails,
+                                      lambda pi, z, out, hid, ctx: _lib.made_family_inverse_rows(
+                                          pi, 'quadratic', z, out, hid, tail_bound=self.tail_bound,
+                                          min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height, ctx=ctx))
+
 
 class MaskedPiecewiseCubicAutoregressiveTransform(AutoregressiveTransform):
     """Monotone piecewise-cubic spline on [-10, 10] (the default interval of models/splines/cubic.py:56-67, which
@@ -413,6 +428,11 @@ class MaskedPiecewiseCubicAutoregressiveTransform(AutoregressiveTransform):
     def _elementwise(self, inputs, params, outputs, logabsdet, inverse):
         _lib.cubic_spline(inputs, params, self.num_bins, tails=None, bound=10.0, inverse=inverse, out=outputs,
                           logabsdet=logabsdet)
+
+    def inverse(self, inputs, context=None):
+        return self._inverse_via_rows(inputs, context, 'cubic', self.num_bins, None,
+                                      lambda pi, z, out, hid, ctx: _lib.made_family_inverse_rows(
+                                          pi, 'cubic', z, out, hid, tail_bound=10.0, ctx=ctx))
 
 
 # ------------------------------------------------------------------------------------ coupling
