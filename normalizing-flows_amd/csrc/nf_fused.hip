@@ -41,6 +41,8 @@ constexpr int HR = 32;                  // epilogue: samples per pass through th
 constexpr int LDT = HR + 4;             // parameter tile [columns][HR + 4], column-major: a lane's 4 consecutive
                                         // accumulator rows go out as one ds_write_b128, conflict-free
 
+constexpr int XOT = 72;            // row stride (floats) of the split GEMM's output staging tile
+
 struct FusedArgs {
     const float* h;          // [M, K] conditioner hidden state
     int64_t ldh;
@@ -69,6 +71,7 @@ struct FusedArgs {
     int n_tiles;             // column tiles computed by this launch, starting at tn0 (window)
     int tn0;
     int feat_limit;          // features >= feat_limit are left untouched (incremental inverse); D = all
+    int vec_out;             // split GEMM: y / residual rows take 16-byte accesses (LDS-staged epilogue)
     int64_t m_tiles;
     int group_m;             // row tiles that share a weight tile back to back (L2 reuse)
     RqsConst c;
@@ -796,6 +799,48 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
     split_k_loop<SP, false, RELU>(g, lds, m0, tn, tid, ws * hs, hs, acc);
     const float oscale = wi * hi;
     float vmax = 0.f;
+    if (g.vec_out) {
+        // 16-byte epilogue: a wave drops 32 rows x its 64 columns into LDS (row stride 72 floats: conflict-free for
+        // the accumulator layout), reads them back four columns per lane and adds the residual / stores with
+        // float4 - 32 loads and 32 stores per wave instead of 128 + 128 four-byte ones, whose residual loads each
+        // waited in front of their store
+        __syncthreads();                                        // (the K loop's stages are dead)
+        float* ot = reinterpret_cast<float*>(lds) + wc * (32 * XOT);
+        const int64_t c0 = (int64_t)tn * FN + wc * 64 + (lane & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ot[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * XOT + j * 32 + (lane & 31)] = acc[i][j][r];
+#pragma unroll
+            for (int qh = 0; qh < 8; qh += 4) {
+                float4 rv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t row = m0 + i * 32 + (qh + q) * 4 + (lane >> 4);
+                    rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.residual && row < g.M && c0 < g.N)
+                        rv[q] = *reinterpret_cast<const float4*>(g.residual + row * g.ldr + c0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t row = m0 + i * 32 + (qh + q) * 4 + (lane >> 4);
+                    float4 v = *reinterpret_cast<const float4*>(ot + ((qh + q) * 4 + (lane >> 4)) * XOT + (lane & 15) * 4);
+                    if (SP::SCALED) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
+                    v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w;
+                    if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (row < g.M && c0 < g.N) {
+                        *reinterpret_cast<float4*>(g.y + row * g.ldy + c0) = v;
+                        const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+                        vmax = fmaxf(fmaxf(vmax, a0 < INFINITY ? a0 : 0.f), a1 < INFINITY ? a1 : 0.f);
+                        vmax = fmaxf(fmaxf(vmax, a2 < INFINITY ? a2 : 0.f), a3 < INFINITY ? a3 : 0.f);
+                    }
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = tn * FN + wc * 64 + j * 32 + (lane & 31);
@@ -1114,7 +1159,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     FusedArgs g;
     g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
-    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max; g.vec_out = 0;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
@@ -1306,7 +1351,10 @@ extern "C" int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, 
     g.residual = residual; g.ldr = res_row_stride; g.relu_out = relu_out; g.out_max = (unsigned*)y_max;
     const int64_t grid = g.m_tiles * nt;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    const size_t lds = (size_t)2 * 2 * split_terms(dtype) * XA;
+    g.vec_out = out % 4 == 0 && y_row_stride % 4 == 0 && ((uintptr_t)y & 15) == 0 &&
+                (!residual || (res_row_stride % 4 == 0 && ((uintptr_t)residual & 15) == 0));
+    const size_t stages = (size_t)2 * 2 * split_terms(dtype) * XA, otile = sizeof(float) * (XT / 64) * 32 * XOT;
+    const size_t lds = g.vec_out && otile > stages ? otile : stages;
     return dtype == NF_DTYPE_BF16X3 ? launch_linear_split<SplitBf16x3>(g, (int)grid, lds, relu_in, s)
                                     : launch_linear_split<SplitF16x2>(g, (int)grid, lds, relu_in, s);
 }
