@@ -47,7 +47,56 @@ struct GemmArgs {
     int tn0;                 // ... starting at this one (tile window; 0 / all for a full layer)
     int64_t m_tiles;
     int vec_a;               // x rows 16-byte aligned and K % 4 == 0
+    int vec_out;             // y / residual / gate / bias take 16-byte accesses (LDS-staged epilogue)
 };
+
+// 16-byte epilogue of the 128 x 128 block kernels: each wave drops 16 rows x its 64 columns of accumulators into LDS
+// (row stride 72 floats: conflict-free for the MFMA C/D layout), reads them back four columns per lane, adds bias /
+// residual, applies ReLU / gate and stores float4.  The 4-byte form issued 64 residual loads per wave, each waiting
+// in front of its store; here the four 16-byte loads of a chunk are in flight together.  `ot`: 4 x 16 x 72 floats.
+constexpr int OT_LD = 72;
+__device__ __forceinline__ void staged_epilogue(const GemmArgs& g, float* ot, const f32x16 (&acc)[2][2], int64_t m0,
+                                                int n0, int wr, int wc, int lane) {
+    __syncthreads();                            // every wave is done with the operand tiles this aliases
+    ot += (wr * 2 + wc) * 16 * OT_LD;
+    const int c0 = n0 + wc * 64 + (lane & 15) * 4;
+    const bool cok = c0 < g.N;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && cok) bv = *reinterpret_cast<const float4*>(g.bias + c0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    ot[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * OT_LD + j * 32 + (lane & 31)] = acc[i][j][8 * c + r];
+            float4 rv[4], gv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t row = m0 + wr * 64 + i * 32 + c * 16 + q * 4 + (lane >> 4);
+                rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                gv[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (row < g.M && cok) {
+                    if (g.res) rv[q] = *reinterpret_cast<const float4*>(g.res + row * g.ldr + c0);
+                    if (g.gate) gv[q] = *reinterpret_cast<const float4*>(g.gate + row * g.ldg + c0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t row = m0 + wr * 64 + i * 32 + c * 16 + q * 4 + (lane >> 4);
+                float4 v = *reinterpret_cast<const float4*>(ot + (q * 4 + (lane >> 4)) * OT_LD + (lane & 15) * 4);
+                v.x = v.x + bv.x + rv[q].x; v.y = v.y + bv.y + rv[q].y; v.z = v.z + bv.z + rv[q].z; v.w = v.w + bv.w + rv[q].w;
+                if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.gate) {
+                    v.x = gv[q].x > 0.f ? v.x : 0.f; v.y = gv[q].y > 0.f ? v.y : 0.f;
+                    v.z = gv[q].z > 0.f ? v.z : 0.f; v.w = gv[q].w > 0.f ? v.w : 0.f;
+                }
+                if (row < g.M && cok) *reinterpret_cast<float4*>(g.y + row * g.ldy + c0) = v;
+            }
+        }
+}
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int64_t& tm, int& tn) {
     // XCD-aware order: blocks that share an XCD (id % 8) get one contiguous run of work items; inside
@@ -206,6 +255,10 @@ __global__ __launch_bounds__(GT, 2) void masked_linear_f32_kernel(const GemmArgs
 
 #undef NF_LOAD_TILE
 
+    if (g.vec_out) {
+        staged_epilogue(g, As, acc, m0, n0, wr, wc, lane);
+        return;
+    }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -361,6 +414,10 @@ __global__ __launch_bounds__(GT, 2) void masked_linear_bf16_kernel(const GemmArg
     }
 #undef NF_LOAD_TILE16
 
+    if (g.vec_out) {
+        staged_epilogue(g, reinterpret_cast<float*>(As), acc, m0, n0, wr, wc, lane);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -652,6 +709,9 @@ static int linear_impl(const float* x, int64_t x_row_stride, const void* packed_
     g.m_tiles = (B + BM - 1) / BM;
     const int vec = dtype == NF_DTYPE_BF16 ? 8 : 4;      // floats per staged chunk
     g.vec_a = (in % vec == 0) && (x_row_stride % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    auto a16 = [](const void* p, int64_t ld) { return p == nullptr || (ld % 4 == 0 && ((uintptr_t)p & 15) == 0); };
+    g.vec_out = out % 4 == 0 && a16(y, y_row_stride) && a16(bias, 0) && a16(residual, residual_row_stride) &&
+                a16(gate, gate_row_stride);
     const int64_t grid = g.m_tiles * g.n_tiles;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
