@@ -266,11 +266,21 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
     const int fv = min(fpt, g.feat_limit - f0);      // features of this tile to evaluate (>= 1 by construction)
 
     // inputs of the tile: consecutive threads take consecutive features of a row
-    for (int i = tid; i < FM * fpt; i += FT) {
-        const int r = i / fpt, f = i - r * fpt;
-        float v = 0.f;
-        if (m0 + r < g.M && f < fv) v = g.x[(m0 + r) * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)];
-        xs[i] = v;
+    {
+        // (all loads in flight at once: as a rolled loop each waited in front of its LDS store)
+        constexpr int NX = (FM * (FN / 11) + FT - 1) / FT;          // fpt <= 256 / 11 (K >= 4)
+        float xv[NX];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int i = tid + q * FT;
+            const int r = i / fpt, f = i - r * fpt;
+            xv[q] = 0.f;
+            if (i < FM * fpt && m0 + r < g.M && f < fv)
+                xv[q] = g.x[(m0 + r) * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)];
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q)
+            if (tid + q * FT < FM * fpt) xs[tid + q * FT] = xv[q];
     }
 
     constexpr int kBK = Stage<BF16>::kBK;
@@ -686,11 +696,22 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
     const int f0 = tn * fpt;
     const int fv = min(fpt, g.feat_limit - f0);
 
-    for (int i = tid; i < XM * fpt; i += XT) {
-        const int r = i / fpt, f = i - r * fpt;
-        float v = 0.f;
-        if (m0 + r < g.M && f < fv) v = g.x[(m0 + r) * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)];
-        xs[i] = v;
+    {
+        // all of the tile's inputs in flight at once (as a rolled loop every load waited in front of its LDS store:
+        // five to six HBM latencies in a row at the head of each workgroup)
+        constexpr int NX = (XM * (FN / 11) + XT - 1) / XT;         // fpt <= 256 / 11 (K >= 4)
+        float xv[NX];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int i = tid + q * XT;
+            const int r = i / fpt, f = i - r * fpt;
+            xv[q] = 0.f;
+            if (i < XM * fpt && m0 + r < g.M && f < fv)
+                xv[q] = g.x[(m0 + r) * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)];
+        }
+#pragma unroll
+        for (int q = 0; q < NX; ++q)
+            if (tid + q * XT < XM * fpt) xs[tid + q * XT] = xv[q];
     }
 
     float ws = 1.f, wi = 1.f, hs = 1.f, hi = 1.f;      // power-of-two scales of the weights / of this launch's hidden state
