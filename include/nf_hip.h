@@ -327,6 +327,13 @@ int nf_masked_linear_bwd_weight(const float* x, int64_t x_row_stride, const floa
                                 int64_t grad_y_row_stride, const float* mask, const int32_t* ktab,
                                 float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
                                 int dtype, void* stream);
+/* The same on split operands (two fp16 terms per value, fp32 accumulation; the NF_DTYPE_F16X2 contract of
+ * nf_masked_linear_split_fwd).  x_max / grad_y_max: slots holding max |x| and max |grad_y| (nf_maxabs or the
+ * y_max of the producing launch).  ACCUMULATING like nf_masked_linear_bwd_weight; no alignment requirement. */
+int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                      const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
+                                      const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,
+                                      int64_t B, int in, int out, int relu_in, void* stream);
 /* Backward of nf_rqs_fwd(inverse=0, feat_index=NULL): from x, params (recomputed, nothing saved from the
  * forward), grad_y[B,D] and grad_logabsdet[B] to grad_x[B,D] (the spline's direct part) and
  * grad_params[B, D*P] (contiguous rows). */

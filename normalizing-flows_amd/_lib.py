@@ -88,6 +88,9 @@ _SIGNATURES = {
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'nf_linear_split_repack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                           _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'nf_masked_linear_split_bwd_weight': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_maxabs': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p]),
     'nf_masked_linear_split_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                               _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
@@ -268,9 +271,10 @@ def maxabs(x):
     return slot
 
 
-def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, out=None):
+def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, out=None, x_max=None):
     """Split-operand hidden-layer GEMM.  The result carries `_nf_max` (slot with max |out|) so that a following
-    split-operand launch needs no pass over it; x's own slot is used when present, else computed here."""
+    split-operand launch needs no pass over it; x's own slot (`x_max`, else x._nf_max) is used when present, else
+    computed here."""
     lib = load()
     _dev(x, 'x')
     xp, xs = _rows(x, 'x')
@@ -281,7 +285,8 @@ def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, ou
         out = torch.empty((B, pls.out), dtype=torch.float32, device=x.device)
     yp, ys = _rows(out, 'out')
     rp, rs = (None, 0) if residual is None else _rows(_dev(residual, 'residual'), 'residual')
-    x_max = getattr(x, '_nf_max', None)
+    if x_max is None:
+        x_max = getattr(x, '_nf_max', None)
     if x_max is None and pls.dtype == NF_DTYPE_F16X2:
         x_max = maxabs(x)
     y_max = torch.empty(1, dtype=torch.int32, device=x.device)
@@ -347,6 +352,30 @@ def masked_linear_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True):
     with torch.cuda.device(x.device):
         _check(lib.nf_masked_linear_bwd_weight(xp, xs, gp, gs, _ptr(m), _ptr(ktab), gw.data_ptr(), _ptr(gb), B, inp, out,
                                                int(relu_in), NF_DTYPE_F32, _stream()), 'nf_masked_linear_bwd_weight')
+    return gw, gb
+
+
+def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True, x_max=None, grad_y_max=None):
+    """masked_linear_bwd_weight on two-term fp16 operands (the f16x2 training mode); the max slots are computed
+    here when the caller has none."""
+    lib = load()
+    _dev(x, 'x')
+    _dev(grad_y, 'grad_y')
+    xp, xs = _rows(x, 'x')
+    gp, gs = _rows(grad_y, 'grad_y')
+    B, inp = x.shape
+    out = grad_y.shape[1]
+    if grad_y.shape[0] != B:
+        raise ValueError('x and grad_y disagree on the batch size')
+    x_max = maxabs(x) if x_max is None else x_max
+    grad_y_max = maxabs(grad_y) if grad_y_max is None else grad_y_max
+    gw = torch.zeros((out, inp), dtype=torch.float32, device=x.device)
+    gb = torch.zeros(out, dtype=torch.float32, device=x.device) if want_bias else None
+    m = None if mask is None else _dev(mask.contiguous(), 'mask')
+    with torch.cuda.device(x.device):
+        _check(lib.nf_masked_linear_split_bwd_weight(xp, xs, x_max.data_ptr(), gp, gs, grad_y_max.data_ptr(), _ptr(m),
+                                                     _ptr(ktab), gw.data_ptr(), _ptr(gb), B, inp, out, int(relu_in),
+                                                     _stream()), 'nf_masked_linear_split_bwd_weight')
     return gw, gb
 
 

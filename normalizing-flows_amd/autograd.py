@@ -22,11 +22,21 @@ def _split_mode(x, width):
     return made.get_matmul_dtype() in made._SPLIT_MODES and _lib.split_gemm_supported(x, width)
 
 
+def _f16x2_mode():
+    from . import made
+    return made.get_matmul_dtype() == 'f16x2'
+
+
 class MaskedLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, layer, relu_in):
+        ctx.x_max = None
         if _split_mode(x, layer.in_features):
-            y = _lib.masked_linear_split(x, layer._packed_linear_split(), residual=residual, relu_in=relu_in)
+            ctx.x_max = getattr(x, '_nf_max', None)
+            if ctx.x_max is None:
+                ctx.x_max = _lib.maxabs(x)
+            y = _lib.masked_linear_split(x, layer._packed_linear_split(), residual=residual, relu_in=relu_in,
+                                         x_max=ctx.x_max)
         else:
             y = _lib.masked_linear(x, layer._packed_linear(), residual=residual, relu_in=relu_in)
         ctx.save_for_backward(x)
@@ -42,17 +52,24 @@ class MaskedLinearFn(torch.autograd.Function):
         layer = ctx.layer
         grad_y = grad_y.contiguous()
         gx = gw = gb = None
+        split_y = _split_mode(grad_y, layer.out_features)
+        gy_max = _lib.maxabs(grad_y) if split_y else None
         if ctx.needs_input_grad[0]:
-            if _split_mode(grad_y, layer.out_features):
+            if split_y:
                 # dX = dY @ (W * mask): the same split-operand kernel on the transposed layer, ReLU gate after it
-                gx = _lib.masked_linear_split(grad_y, layer._packed_linear_split_t())
+                gx = _lib.masked_linear_split(grad_y, layer._packed_linear_split_t(), x_max=gy_max)
                 if ctx.relu_in:
                     gx.mul_(x > 0)
             else:
                 gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if ctx.relu_in else None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _lib.masked_linear_bwd_weight(x, grad_y, getattr(layer, 'mask', None), layer._packed_linear().ktab,
-                                                   ctx.relu_in, want_bias=ctx.has_bias)
+            if split_y and ctx.x_max is not None and _f16x2_mode():
+                gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
+                                                             layer._packed_linear().ktab, ctx.relu_in,
+                                                             want_bias=ctx.has_bias, x_max=ctx.x_max, grad_y_max=gy_max)
+            else:
+                gw, gb = _lib.masked_linear_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
+                                                       layer._packed_linear().ktab, ctx.relu_in, want_bias=ctx.has_bias)
         gres = grad_y if ctx.has_residual else None
         return gx, gw, gb, gres, None, None
 

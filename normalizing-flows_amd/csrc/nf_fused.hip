@@ -889,6 +889,178 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
     }
 }
 
+// Weight gradient on split operands (two fp16 terms): grad_W[n, k] += mask[n, k] * sum_b grad_y[b, n] * act(x[b, k]),
+// a TN GEMM whose reduction runs over the batch.  128 x 128 output tiles, the batch in chunks of 32 rows and split
+// over gridDim.z (fp32 atomics), fully masked tiles skipped through the forward K-tile table.  The MFMA wants 8
+// consecutive batch rows of one column per lane, so a thread reads its column for 8 rows (one 4-byte load per
+// row, coalesced across the 128 columns), splits the 8 values and stores them as one 16-byte row piece of the
+// transposed LDS tile [term][column][32 rows + pad].  Both operands are power-of-two scaled from their max |.|.
+constexpr int WSB = 32;              // batch rows per step
+constexpr int WSLD = WSB + 8;        // fp16 elements per LDS row (80 bytes: conflict-free 16-byte operand reads)
+
+struct WgradSplitArgs {
+    const float* x;
+    int64_t ldx;
+    const float* gy;
+    int64_t ldgy;
+    const unsigned* x_max;
+    const unsigned* gy_max;
+    const float* mask;
+    const int32_t* ktab;     // nullable: forward K-tile table [out/128][2] in 32-wide units
+    float* gw;
+    float* gb;               // nullable: column sums of grad_y, accumulated by the tk == 0 blocks
+    int64_t M;
+    int out, in, relu_in, splits;
+    int nt, kt, group;       // tiles along out / in; consecutive work items kept on one XCD
+};
+
+// Work item w = (split * nt + tn) * kt + tk.  Workgroups go round-robin over the 8 XCDs by their linear id, so the
+// id is folded such that `group` consecutive items (all K tiles of up to 8 output tiles of one batch split: they
+// read the same grad_y / x chunks at the same time) land on ONE XCD and share its L2.
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradSplitArgs g) {
+    typedef SplitF16x2 SP;
+    __shared__ __attribute__((aligned(16))) _Float16 Yt[2 * 128 * WSLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Xt[2 * 128 * WSLD];
+    const int slot = blockIdx.x >> 3;
+    const int64_t w = ((int64_t)(slot / g.group) * 8 + (blockIdx.x & 7)) * g.group + slot % g.group;
+    if (w >= (int64_t)g.nt * g.kt * g.splits) return;
+    // output tiles from the last one down: under MADE's masks those have the most unmasked K tiles (long items first)
+    const int tk = (int)(w % g.kt), tn = g.nt - 1 - (int)((w / g.kt) % g.nt), split = (int)(w / ((int64_t)g.kt * g.nt));
+    const int n0 = tn * 128, k0 = tk * 128;
+    const bool do_bias = g.gb != nullptr && tk == 0;
+    bool masked_out = false;
+    if (g.ktab) {
+        const int kb = g.ktab[2 * tn] * 32, ke = g.ktab[2 * tn + 1] * 32;
+        masked_out = k0 >= ke || k0 + 128 <= kb;
+    }
+    if (masked_out && !do_bias) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t per = ((g.M + g.splits - 1) / g.splits + WSB - 1) / WSB * WSB;
+    const int64_t b_begin = (int64_t)split * per, b_end = min(g.M, b_begin + per);
+    if (b_begin >= b_end) return;
+    if (masked_out) {        // bias only: this block's column sums of grad_y
+        const int c = tid & 127;
+        if (n0 + c < g.out) {
+            float s = 0.f;
+            for (int64_t b = b_begin + (tid >> 7); b < b_end; b += 2) s += g.gy[b * g.ldgy + n0 + c];
+            atomicAdd(&g.gb[n0 + c], s);
+        }
+        return;
+    }
+    float sy, iy, sx, ix;
+    pow2_pair(*g.gy_max, sy, iy);
+    pow2_pair(*g.x_max, sx, ix);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // staging: thread = column (tid & 127) x row octets (tid >> 7) and (tid >> 7) + 2 of the 32-row chunk.  Columns
+    // past the matrix edge are clamped, not zeroed: they only reach accumulator entries that are never stored.
+    // A load is a buffer load: descriptor on the chunk (scalar), this lane's constant byte offset (its column),
+    // the row's offset in a scalar register - no vector address arithmetic.  Rows past the batch end are clamped
+    // to the last row and grad_y's scale for them is 0 (all scalar work), so the tail costs the lanes nothing.
+    const int sc = tid & 127, so = tid >> 7;
+    const int so_u = __builtin_amdgcn_readfirstlane(so);                 // uniform per wave
+    const int yc = min(n0 + sc, g.out - 1), xc = min(k0 + sc, g.in - 1);
+    const bool yok = n0 + sc < g.out;
+    const int ldy4 = (int)g.ldgy * 4, ldx4 = (int)g.ldx * 4;
+    struct Chunk { float y[2][8], x[2][8]; };
+    auto load_chunk = [&](Chunk& c, int64_t b0) {
+        const __amdgpu_buffer_rsrc_t ry =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.gy + b0 * g.ldgy), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + b0 * g.ldx), 0, 0x7fffffff, 0x00020000);
+        const int last = (int)min((int64_t)WSB, b_end - b0) - 1;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = min((so_u + 2 * o) * 8 + e, last);
+                c.y[o][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yc * 4, r * ldy4, 0));
+                c.x[o][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xc * 4, r * ldx4, 0));
+            }
+    };
+    const int fr = lane & 31, fb = lane >> 5;
+    float bsum = 0.f;                                // in grad_y's scaled units
+    // one step: chunk c (rows b0 ..) -> split terms -> LDS -> refill c with the chunk two steps ahead -> MFMA
+    auto step = [&](Chunk& c, int64_t b0) {
+        const int left = (int)min((int64_t)WSB, b_end - b0);
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            SP::vec ty[2], tx[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                SP::elem t[2];
+                const float ys = c.y[o][e] * ((so_u + 2 * o) * 8 + e < left ? sy : 0.f);
+                bsum += ys;
+                SP::split1(ys, t);
+                ty[0][e] = t[0]; ty[1][e] = t[1];
+                const float xa = g.relu_in ? __builtin_amdgcn_fmed3f(c.x[o][e], 0.f, INFINITY) : c.x[o][e];
+                SP::split1(xa * sx, t);
+                tx[0][e] = t[0]; tx[1][e] = t[1];
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                *reinterpret_cast<SP::vec*>(&Yt[(p * 128 + sc) * WSLD + (so + 2 * o) * 8]) = ty[p];
+                *reinterpret_cast<SP::vec*>(&Xt[(p * 128 + sc) * WSLD + (so + 2 * o) * 8]) = tx[p];
+            }
+        }
+        __syncthreads();
+        if (b0 + 2 * WSB < b_end) load_chunk(c, b0 + 2 * WSB);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < WSB / 16; ++ks) {
+            SP::vec a[2][2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    a[i][p] = *reinterpret_cast<const SP::vec*>(&Yt[(p * 128 + wr * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
+                    b[i][p] = *reinterpret_cast<const SP::vec*>(&Xt[(p * 128 + wc * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) SP::fma_tile(acc[i][j], a[i], b[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Chunk c0, c1;                                    // two chunks in flight: a load has a whole step to land
+    load_chunk(c0, b_begin);
+    if (b_begin + WSB < b_end) load_chunk(c1, b_begin + WSB);
+    for (int64_t b0 = b_begin; b0 < b_end; b0 += 2 * WSB) {
+        step(c0, b0);
+        if (b0 + WSB < b_end) step(c1, b0 + WSB);
+    }
+    bsum *= iy;
+    if (do_bias && yok) atomicAdd(&g.gb[n0 + sc], bsum);
+    const float oscale = iy * ix;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wc * 64 + j * 32 + (lane & 31);
+            if (k >= g.in) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n >= g.out) continue;
+                const int64_t idx = (int64_t)n * g.in + k;
+                float v = acc[i][j][r] * oscale;
+                if (g.mask) v *= g.mask[idx];
+                if (g.splits > 1) atomicAdd(&g.gw[idx], v);
+                else g.gw[idx] += v;
+            }
+        }
+}
+
 // packed[tile][step][wave 0..3][j 0..1][term][lane 0..63][8]: the 8 elements lane `lane` feeds to the MFMA as
 // the B operand of column block j of wave `wave` - row = wave*64 + j*32 + (lane & 31) of the tile,
 // k = step*16 + (lane >> 5)*8 + e - i.e. term t of W[n][k] * mask * fold (* the scale slot's power of two)
@@ -955,17 +1127,40 @@ __global__ void maxabs_kernel(const float* __restrict__ W, const float* __restri
 __global__ __launch_bounds__(256) void maxabs_rows_kernel(const float* __restrict__ h, int64_t ldh, int64_t M, int K,
                                                           unsigned* __restrict__ slot) {
     const int cpr = K / 4;
-    const int64_t total = M * cpr;
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / cpr;
-        const float4 v = *reinterpret_cast<const float4*>(h + r * ldh + (i - r * cpr) * 4);
+    auto take = [&](const float4 v) {
         const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));   // fmaxf drops NaN
         m = fmaxf(m, a < INFINITY ? a : 0.f);
+    };
+    if (ldh == K) {                                  // contiguous: one flat array, 4 independent loads in flight
+        const int64_t total = M * cpr, stride = (int64_t)gridDim.x * 256;
+        const float4* p = reinterpret_cast<const float4*>(h);
+        int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < total; i += 4 * stride) {
+            const float4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], e = p[i + 3 * stride];
+            take(a); take(b); take(c); take(e);
+        }
+        for (; i < total; i += stride) take(p[i]);
+    } else {                                         // strided rows: a workgroup walks 4 rows at a time
+        for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < M; r0 += (int64_t)gridDim.x * 4)
+            for (int c = threadIdx.x; c < cpr; c += 256) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[u] = *reinterpret_cast<const float4*>(h + min(r0 + u, M - 1) * ldh + c * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) take(v[u]);
+            }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+    __shared__ float wm[4];                          // one atomic per workgroup: they all hit the same address
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f) atomicMax(slot, __float_as_uint(m));
+    }
 }
 
 // h[M][K] fp32 -> NT term planes [NT][M][kp16], kp16 = K rounded up to whole 16-wide steps (zero filled)
@@ -1028,7 +1223,7 @@ inline int maxabs_rows(const float* h, int64_t ld, int64_t B, int cols, unsigned
     hipError_t me = hipMemsetAsync(slot, 0, sizeof(unsigned), s);
     if (me != hipSuccess) return (int)me;
     const int64_t q4 = B * (cols / 4);
-    const int mgrid = (int)((q4 + 255) / 256 < 4096 ? (q4 + 255) / 256 : 4096);
+    const int mgrid = (int)((q4 + 255) / 256 < 2048 ? (q4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(maxabs_rows_kernel, dim3(mgrid), dim3(256), 0, s, h, ld, B, cols, slot);
     return nf_launch_status();
 }
@@ -1378,4 +1573,34 @@ extern "C" int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, 
     const size_t lds = g.vec_out && otile > stages ? otile : stages;
     return dtype == NF_DTYPE_BF16X3 ? launch_linear_split<SplitBf16x3>(g, (int)grid, lds, relu_in, s)
                                     : launch_linear_split<SplitF16x2>(g, (int)grid, lds, relu_in, s);
+}
+
+extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                                 const float* grad_y, int64_t grad_y_row_stride,
+                                                 const uint32_t* grad_y_max, const float* mask, const int32_t* ktab,
+                                                 float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
+                                                 void* stream) {
+    if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
+    if (B == 0) return NF_OK;
+    if (!x || !grad_y || !grad_w || !x_max || !grad_y_max) return NF_ERR_NULL;
+    if (x_row_stride < in || grad_y_row_stride < out) return NF_ERR_LAYOUT;
+    if (x_row_stride > (1 << 24) || grad_y_row_stride > (1 << 24)) return NF_ERR_LAYOUT;     // 32-bit offsets within a chunk
+    WgradSplitArgs g;
+    g.x = x; g.ldx = x_row_stride; g.gy = grad_y; g.ldgy = grad_y_row_stride; g.x_max = (const unsigned*)x_max;
+    g.gy_max = (const unsigned*)grad_y_max; g.mask = mask; g.ktab = ktab; g.gw = grad_w; g.gb = grad_b; g.M = B; g.out = out; g.in = in;
+    g.relu_in = relu_in;
+    const int nt = (out + 127) / 128, kt = (in + 127) / 128;
+    int64_t splits = 3072 / ((int64_t)nt * kt) + 1;
+    if (splits < 1) splits = 1;
+    const int64_t max_splits = (B + 8 * WSB - 1) / (8 * WSB);
+    if (splits > max_splits) splits = max_splits;
+    g.splits = (int)splits;
+    g.nt = nt; g.kt = kt;
+    g.group = kt * (64 / kt < 1 ? 1 : (64 / kt < nt ? 64 / kt : nt));
+    const int64_t work = (int64_t)nt * kt * splits;
+    const int64_t grid = (work + g.group - 1) / g.group * g.group;      // whole groups, then whole rounds of 8 XCDs
+    const int64_t blocks = (grid / g.group + 7) / 8 * 8 * g.group;
+    if (blocks > 0x7fffffff) return NF_ERR_SHAPE;
+    hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    return nf_launch_status();
 }

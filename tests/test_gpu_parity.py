@@ -836,14 +836,50 @@ def test_training_gradients_match_autograd_of_the_oracle(nf, D, H, K, B):
 
 @pytest.mark.parametrize('mode', ['f16x2', 'bf16x3'])
 def test_training_gradients_in_split_operand_modes(nf, mode):
-    """The same gradient check with the forward and input-gradient GEMMs on the split-operand kernel (weight
-    gradients stay on fp32 MFMA): the fp32 bars hold."""
+    """The same gradient check with the forward and input-gradient GEMMs on the split-operand kernel (in f16x2
+    mode the weight gradients too; in bf16x3 mode they stay on fp32 MFMA): the fp32 bars hold."""
     nf.set_matmul_dtype(mode)
     try:
         test_training_gradients_match_autograd_of_the_oracle(nf, 40, 136, 4, 130)
         test_training_gradients_match_autograd_of_the_oracle(nf, 16, 32, 8, 96)
     finally:
         nf.set_matmul_dtype('f32')
+
+
+@pytest.mark.parametrize('B,inp,out,relu_in,masked,bias', [
+    (130, 40, 136, True, True, True), (4096, 256, 384, False, True, True), (37, 8, 8, True, False, False),
+    (20000, 128, 392, True, True, True), (1, 16, 24, False, False, True)])
+def test_split_operand_weight_gradient(nf, B, inp, out, relu_in, masked, bias):
+    """nf_masked_linear_split_bwd_weight (two fp16 terms per operand, fp32 accumulate) against float64 torch:
+    grad_W = mask * grad_y^T @ act(x), grad_b = column sums; ragged tiles, batch tails, masked tiles skipped
+    through the K-tile table (lower-triangular mask as MADE's), wide dynamic range in both operands."""
+    from normalizing_flows_amd import _lib
+    g = torch.Generator().manual_seed(B + inp)
+    x = torch.randn(B, inp, generator=g) * torch.logspace(-3, 1, inp)
+    gy = torch.randn(B, out, generator=g) * 1e-4 * torch.logspace(0, -3, out)
+    mask = None
+    ktab = None
+    if masked:
+        deg_in = torch.arange(inp) * 10 // inp
+        deg_out = torch.arange(out) * 10 // out
+        mask = (deg_out[:, None] >= deg_in[None, :]).float()
+        pl = _lib.PackedLinear(torch.zeros(out, inp).cuda(), mask.cuda(), None, _lib.NF_DTYPE_F32)
+        ktab = pl.ktab
+    gw, gb = _lib.masked_linear_split_bwd_weight(x.cuda(), gy.cuda(), None if mask is None else mask.cuda(), ktab,
+                                                 relu_in, want_bias=bias)
+    a = x.double().clamp_min(0) if relu_in else x.double()
+    want = gy.double().t() @ a
+    if mask is not None:
+        want = want * mask.double()
+        assert (gw.cpu()[mask == 0] == 0).all()
+    # per-entry bar: the fp32 accumulation error of a length-B dot product, relative to sum |terms|
+    bound = (gy.double().abs().t() @ a.abs()) * 2e-6 + 1e-30
+    assert ((gw.cpu().double() - want).abs() <= bound).all(), ((gw.cpu().double() - want).abs() / bound).max()
+    if bias:
+        wb = gy.double().sum(0)
+        assert ((gb.cpu().double() - wb).abs() <= gy.double().abs().sum(0) * 2e-6 + 1e-30).all()
+    else:
+        assert gb is None
 
 
 def test_short_training_run_lowers_the_loss(nf):
