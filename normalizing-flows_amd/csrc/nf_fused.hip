@@ -1105,22 +1105,28 @@ __global__ void pack_fused_split_kernel(const float* __restrict__ W, const float
 
 // scale slot (after the K-range table): the bit pattern of max |W * mask * fold| (positive floats order like
 // unsigned integers, so atomicMax works on the bits); consumers derive the power of two with pow2_pair.
-__global__ void maxabs_kernel(const float* __restrict__ W, const float* __restrict__ mask, int64_t total, int P, int in,
-                              int n_logits, float logit_fold, unsigned* __restrict__ slot) {
+__global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ W, const float* __restrict__ mask,
+                                                     int64_t total, int P, int in, int n_logits, float logit_fold,
+                                                     unsigned* __restrict__ slot) {
+    const int out = (int)(total / in);
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = W[i];
-        if (mask) v *= mask[i];
-        if ((int)((i / in) % P) < n_logits) v *= logit_fold;
-        m = fmaxf(m, fabsf(v));
+    for (int r = blockIdx.x; r < out; r += gridDim.x) {           // a workgroup per weight row: the fold is per row
+        const float fold = (r % P) < n_logits ? logit_fold : 1.0f;
+        const float* __restrict__ w = W + (int64_t)r * in;
+        const float* __restrict__ k = mask ? mask + (int64_t)r * in : nullptr;
+        float mr = 0.f;
+        for (int c = threadIdx.x; c < in; c += 256) mr = fmaxf(mr, fabsf(k ? w[c] * k[c] : w[c]));
+        m = fmaxf(m, mr * fabsf(fold));
     }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 8, 64));
-    m = fmaxf(m, __shfl_xor(m, 4, 64));
-    m = fmaxf(m, __shfl_xor(m, 2, 64));
-    m = fmaxf(m, __shfl_xor(m, 1, 64));
-    if ((threadIdx.x & 63) == 0 && m == m && m < INFINITY) atomicMax(slot, __float_as_uint(m));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    __shared__ float wm[4];                          // one atomic per workgroup: they all hit the same address
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f && m < INFINITY) atomicMax(slot, __float_as_uint(m));
+    }
 }
 
 // largest finite |h| of h[M][K] into slot[0] (bit pattern, see above)
@@ -1330,7 +1336,7 @@ extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const 
         hipError_t me = hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), s);
         if (me != hipSuccess) return (int)me;
         const int64_t nw = (int64_t)out * in;
-        const int mgrid = (int)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
+        const int mgrid = out < 1024 ? out : 1024;
         hipLaunchKernelGGL(maxabs_kernel, dim3(mgrid), dim3(256), 0, s, W, mask, nw, P, in, 2 * K, logit_fold, slot);
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitF16x2>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in,
                            fpt * P, kpad, 2 * total, P, 2 * K, logit_fold, (const unsigned*)slot, (_Float16*)packed,
@@ -1494,7 +1500,7 @@ static int linear_split_pack_impl(const float* W, const float* mask, const float
     if (me != hipSuccess) return (int)me;
     if (dtype == NF_DTYPE_F16X2) {
         const int64_t nw = (int64_t)out * in;
-        const int mgrid = (int)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048);
+        const int mgrid = out < 1024 ? out : 1024;
         hipLaunchKernelGGL(maxabs_kernel, dim3(mgrid), dim3(256), 0, s, W, mask, nw, 1, in, 0, 1.0f, slot);
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitF16x2>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
                            kpad, total, 1, 0, 1.0f, (const unsigned*)slot, (_Float16*)packed, bias_packed);
