@@ -917,21 +917,31 @@ struct WgradSplitArgs {
 // Work item w = (split * nt + tn) * kt + tk.  Workgroups go round-robin over the 8 XCDs by their linear id, so the
 // id is folded such that `group` consecutive items (all K tiles of up to 8 output tiles of one batch split: they
 // read the same grad_y / x chunks at the same time) land on ONE XCD and share its L2.
-__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradSplitArgs g) {
+// TW = 1: 128 (out) x 128 (in) tiles, 4 waves, two workgroups per CU; TW = 2: 256 x 128 tiles, 8 waves, one workgroup per
+// CU (wide layers: a quarter fewer loads and splits per product, grad_y chunks shared by half as many workgroups).
+template <int TW>
+__global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const WgradSplitArgs g) {
     typedef SplitF16x2 SP;
-    __shared__ __attribute__((aligned(16))) _Float16 Yt[2 * 128 * WSLD];
+    constexpr int YC = 128 * TW;                     // grad_y columns (output rows of grad_W) per tile
+    constexpr int XO = 2 / TW;                       // x row octets per thread
+    __shared__ __attribute__((aligned(16))) _Float16 Yt[2 * YC * WSLD];
     __shared__ __attribute__((aligned(16))) _Float16 Xt[2 * 128 * WSLD];
     const int slot = blockIdx.x >> 3;
     const int64_t w = ((int64_t)(slot / g.group) * 8 + (blockIdx.x & 7)) * g.group + slot % g.group;
     if (w >= (int64_t)g.nt * g.kt * g.splits) return;
     // output tiles from the last one down: under MADE's masks those have the most unmasked K tiles (long items first)
     const int tk = (int)(w % g.kt), tn = g.nt - 1 - (int)((w / g.kt) % g.nt), split = (int)(w / ((int64_t)g.kt * g.nt));
-    const int n0 = tn * 128, k0 = tk * 128;
+    const int n0 = tn * YC, k0 = tk * 128;
     const bool do_bias = g.gb != nullptr && tk == 0;
     bool masked_out = false;
-    if (g.ktab) {
-        const int kb = g.ktab[2 * tn] * 32, ke = g.ktab[2 * tn + 1] * 32;
-        masked_out = k0 >= ke || k0 + 128 <= kb;
+    if (g.ktab) {                                    // the table is per 128 output rows: this tile spans TW entries
+        masked_out = true;
+#pragma unroll
+        for (int u = 0; u < TW; ++u) {
+            if ((tn * TW + u) * 128 >= g.out) break;
+            const int kb = g.ktab[2 * (tn * TW + u)] * 32, ke = g.ktab[2 * (tn * TW + u) + 1] * 32;
+            if (k0 < ke && k0 + 128 > kb) masked_out = false;
+        }
     }
     if (masked_out && !do_bias) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -940,10 +950,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradSplitArg
     const int64_t b_begin = (int64_t)split * per, b_end = min(g.M, b_begin + per);
     if (b_begin >= b_end) return;
     if (masked_out) {        // bias only: this block's column sums of grad_y
-        const int c = tid & 127;
+        const int c = tid % YC;
         if (n0 + c < g.out) {
             float s = 0.f;
-            for (int64_t b = b_begin + (tid >> 7); b < b_end; b += 2) s += g.gy[b * g.ldgy + n0 + c];
+            for (int64_t b = b_begin + tid / YC; b < b_end; b += 2) s += g.gy[b * g.ldgy + n0 + c];
             atomicAdd(&g.gb[n0 + c], s);
         }
         return;
@@ -960,17 +970,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradSplitArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // staging: thread = column (tid & 127) x row octets (tid >> 7) and (tid >> 7) + 2 of the 32-row chunk.  Columns
+    // staging: grad_y thread = column (tid % YC) x row octets (tid / YC) and (tid / YC) + 2 of the 32-row chunk; x
+    // thread = column (tid & 127) x octets (tid >> 7) + 2 TW o.  Columns
     // past the matrix edge are clamped, not zeroed: they only reach accumulator entries that are never stored.
     // A load is a buffer load: descriptor on the chunk (scalar), this lane's constant byte offset (its column),
     // the row's offset in a scalar register - no vector address arithmetic.  Rows past the batch end are clamped
     // to the last row and grad_y's scale for them is 0 (all scalar work), so the tail costs the lanes nothing.
-    const int sc = tid & 127, so = tid >> 7;
+    const int sc = tid % YC, so = tid / YC, xsc = tid & 127, xso = tid >> 7;
     const int so_u = __builtin_amdgcn_readfirstlane(so);                 // uniform per wave
-    const int yc = min(n0 + sc, g.out - 1), xc = min(k0 + sc, g.in - 1);
+    const int xso_u = __builtin_amdgcn_readfirstlane(xso);
+    const int yc = min(n0 + sc, g.out - 1), xc = min(k0 + xsc, g.in - 1);
     const bool yok = n0 + sc < g.out;
     const int ldy4 = (int)g.ldgy * 4, ldx4 = (int)g.ldx * 4;
-    struct Chunk { float y[2][8], x[2][8]; };
+    struct Chunk { float y[2][8], x[XO][8]; };
     auto load_chunk = [&](Chunk& c, int64_t b0) {
         const __amdgpu_buffer_rsrc_t ry =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.gy + b0 * g.ldgy), 0, 0x7fffffff, 0x00020000);
@@ -983,6 +995,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradSplitArg
             for (int e = 0; e < 8; ++e) {
                 const int r = min((so_u + 2 * o) * 8 + e, last);
                 c.y[o][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yc * 4, r * ldy4, 0));
+            }
+#pragma unroll
+        for (int o = 0; o < XO; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = min((xso_u + 2 * TW * o) * 8 + e, last);
                 c.x[o][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xc * 4, r * ldx4, 0));
             }
     };
@@ -994,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradSplitArg
         __syncthreads();
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            SP::vec ty[2], tx[2];
+            SP::vec ty[2];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 SP::elem t[2];
@@ -1002,15 +1020,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradSplitArg
                 bsum += ys;
                 SP::split1(ys, t);
                 ty[0][e] = t[0]; ty[1][e] = t[1];
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<SP::vec*>(&Yt[(p * YC + sc) * WSLD + (so + 2 * o) * 8]) = ty[p];
+        }
+#pragma unroll
+        for (int o = 0; o < XO; ++o) {
+            SP::vec tx[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                SP::elem t[2];
                 const float xa = g.relu_in ? __builtin_amdgcn_fmed3f(c.x[o][e], 0.f, INFINITY) : c.x[o][e];
                 SP::split1(xa * sx, t);
                 tx[0][e] = t[0]; tx[1][e] = t[1];
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                *reinterpret_cast<SP::vec*>(&Yt[(p * 128 + sc) * WSLD + (so + 2 * o) * 8]) = ty[p];
-                *reinterpret_cast<SP::vec*>(&Xt[(p * 128 + sc) * WSLD + (so + 2 * o) * 8]) = tx[p];
-            }
+            for (int p = 0; p < 2; ++p)
+                *reinterpret_cast<SP::vec*>(&Xt[(p * 128 + xsc) * WSLD + (xso + 2 * TW * o) * 8]) = tx[p];
         }
         __syncthreads();
         if (b0 + 2 * WSB < b_end) load_chunk(c, b0 + 2 * WSB);
@@ -1022,7 +1049,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(const WgradSplitArg
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    a[i][p] = *reinterpret_cast<const SP::vec*>(&Yt[(p * 128 + wr * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
+                    a[i][p] = *reinterpret_cast<const SP::vec*>(&Yt[(p * YC + wr * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
                     b[i][p] = *reinterpret_cast<const SP::vec*>(&Xt[(p * 128 + wc * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
                 }
 #pragma unroll
@@ -1595,18 +1622,23 @@ extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_s
     g.x = x; g.ldx = x_row_stride; g.gy = grad_y; g.ldgy = grad_y_row_stride; g.x_max = (const unsigned*)x_max;
     g.gy_max = (const unsigned*)grad_y_max; g.mask = mask; g.ktab = ktab; g.gw = grad_w; g.gb = grad_b; g.M = B; g.out = out; g.in = in;
     g.relu_in = relu_in;
-    const int nt = (out + 127) / 128, kt = (in + 127) / 128;
-    int64_t splits = 3072 / ((int64_t)nt * kt) + 1;
+    const int tw = out >= 2048 ? 2 : 1;                                  // wide layers: 256-row tiles, one workgroup per CU
+    const int nt = (out + 128 * tw - 1) / (128 * tw), kt = (in + 127) / 128;
+    int64_t splits = 3072 / tw / ((int64_t)nt * kt) + 1;
     if (splits < 1) splits = 1;
     const int64_t max_splits = (B + 8 * WSB - 1) / (8 * WSB);
     if (splits > max_splits) splits = max_splits;
     g.splits = (int)splits;
     g.nt = nt; g.kt = kt;
-    g.group = kt * (64 / kt < 1 ? 1 : (64 / kt < nt ? 64 / kt : nt));
+    const int resident = 64 / tw;                                        // workgroups one XCD holds at a time
+    g.group = kt * (resident / kt < 1 ? 1 : (resident / kt < nt ? resident / kt : nt));
     const int64_t work = (int64_t)nt * kt * splits;
     const int64_t grid = (work + g.group - 1) / g.group * g.group;      // whole groups, then whole rounds of 8 XCDs
     const int64_t blocks = (grid / g.group + 7) / 8 * 8 * g.group;
     if (blocks > 0x7fffffff) return NF_ERR_SHAPE;
-    hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    if (tw == 2)
+        hipLaunchKernelGGL(wgrad_split_kernel<2>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(wgrad_split_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     return nf_launch_status();
 }
