@@ -924,8 +924,10 @@ __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const Wgr
     typedef SplitF16x2 SP;
     constexpr int YC = 128 * TW;                     // grad_y columns (output rows of grad_W) per tile
     constexpr int XO = 2 / TW;                       // x row octets per thread
-    __shared__ __attribute__((aligned(16))) _Float16 Yt[2 * YC * WSLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Xt[2 * 128 * WSLD];
+    constexpr int YSZ = 2 * YC * WSLD, XSZ = 2 * 128 * WSLD;            // one buffer: both term planes, fp16 elements
+    extern __shared__ __attribute__((aligned(16))) char wg_lds[];
+    _Float16* const Yt = (_Float16*)wg_lds;                             // [2 buffers][2 terms][YC][WSLD]
+    _Float16* const Xt = Yt + 2 * YSZ;                                  // [2 buffers][2 terms][128][WSLD]
     const int slot = blockIdx.x >> 3;
     const int64_t w = ((int64_t)(slot / g.group) * 8 + (blockIdx.x & 7)) * g.group + slot % g.group;
     if (w >= (int64_t)g.nt * g.kt * g.splits) return;
@@ -1006,10 +1008,11 @@ __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const Wgr
     };
     const int fr = lane & 31, fb = lane >> 5;
     float bsum = 0.f;                                // in grad_y's scaled units
-    // one step: chunk c (rows b0 ..) -> split terms -> LDS -> refill c with the chunk two steps ahead -> MFMA
-    auto step = [&](Chunk& c, int64_t b0) {
+    // chunk c (rows b0 ..) -> split terms -> LDS buffer `buf`
+    auto convert = [&](const Chunk& c, int64_t b0, int buf) {
         const int left = (int)min((int64_t)WSB, b_end - b0);
-        __syncthreads();
+        _Float16* const yt = Yt + buf * YSZ;
+        _Float16* const xt = Xt + buf * XSZ;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             SP::vec ty[2];
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const Wgr
             }
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                *reinterpret_cast<SP::vec*>(&Yt[(p * YC + sc) * WSLD + (so + 2 * o) * 8]) = ty[p];
+                *reinterpret_cast<SP::vec*>(&yt[(p * YC + sc) * WSLD + (so + 2 * o) * 8]) = ty[p];
         }
 #pragma unroll
         for (int o = 0; o < XO; ++o) {
@@ -1037,11 +1040,12 @@ __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const Wgr
             }
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                *reinterpret_cast<SP::vec*>(&Xt[(p * 128 + xsc) * WSLD + (xso + 2 * TW * o) * 8]) = tx[p];
+                *reinterpret_cast<SP::vec*>(&xt[(p * 128 + xsc) * WSLD + (xso + 2 * TW * o) * 8]) = tx[p];
         }
-        __syncthreads();
-        if (b0 + 2 * WSB < b_end) load_chunk(c, b0 + 2 * WSB);
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma = [&](int buf) {
+        const _Float16* const yt = Yt + buf * YSZ;
+        const _Float16* const xt = Xt + buf * XSZ;
 #pragma unroll
         for (int ks = 0; ks < WSB / 16; ++ks) {
             SP::vec a[2][2], b[2][2];
@@ -1049,22 +1053,42 @@ __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const Wgr
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    a[i][p] = *reinterpret_cast<const SP::vec*>(&Yt[(p * YC + wr * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
-                    b[i][p] = *reinterpret_cast<const SP::vec*>(&Xt[(p * 128 + wc * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
+                    a[i][p] = *reinterpret_cast<const SP::vec*>(&yt[(p * YC + wr * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
+                    b[i][p] = *reinterpret_cast<const SP::vec*>(&xt[(p * 128 + wc * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) SP::fma_tile(acc[i][j], a[i], b[j]);
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
-    Chunk c0, c1;                                    // two chunks in flight: a load has a whole step to land
+    // One barrier per step: while the MFMAs run on buffer s & 1, the same waves split chunk s + 1 into the other
+    // buffer (its last readers passed the previous barrier) and refill that chunk's registers with chunk s + 3.
+    Chunk c0, c1;
     load_chunk(c0, b_begin);
     if (b_begin + WSB < b_end) load_chunk(c1, b_begin + WSB);
+    convert(c0, b_begin, 0);
+    if (b_begin + 2 * WSB < b_end) load_chunk(c0, b_begin + 2 * WSB);
+    __syncthreads();
+    // The two waves that share a SIMD (w and w + 4 with 8 waves) take the two halves of a step in opposite order,
+    // so one splits on the vector ALU while the other's MFMAs run.
+    const bool mma_first = TW == 2 && __builtin_amdgcn_readfirstlane(wave >> 2) != 0;
     for (int64_t b0 = b_begin; b0 < b_end; b0 += 2 * WSB) {
-        step(c0, b0);
-        if (b0 + WSB < b_end) step(c1, b0 + WSB);
+        if (mma_first) { mma(0); __builtin_amdgcn_sched_barrier(0); }
+        if (b0 + WSB < b_end) {
+            convert(c1, b0 + WSB, 1);
+            if (b0 + 3 * WSB < b_end) load_chunk(c1, b0 + 3 * WSB);
+        }
+        if (!mma_first) { __builtin_amdgcn_sched_barrier(0); mma(0); }
+        __syncthreads();
+        if (b0 + WSB >= b_end) break;
+        if (mma_first) { mma(1); __builtin_amdgcn_sched_barrier(0); }
+        if (b0 + 2 * WSB < b_end) {
+            convert(c0, b0 + 2 * WSB, 0);
+            if (b0 + 4 * WSB < b_end) load_chunk(c0, b0 + 4 * WSB);
+        }
+        if (!mma_first) { __builtin_amdgcn_sched_barrier(0); mma(1); }
+        __syncthreads();
     }
     bsum *= iy;
     if (do_bias && yok) atomicAdd(&g.gb[n0 + sc], bsum);
@@ -1636,9 +1660,20 @@ extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_s
     const int64_t grid = (work + g.group - 1) / g.group * g.group;      // whole groups, then whole rounds of 8 XCDs
     const int64_t blocks = (grid / g.group + 7) / 8 * 8 * g.group;
     if (blocks > 0x7fffffff) return NF_ERR_SHAPE;
+    static bool attr_set = false;          // raise the dynamic-LDS cap once (not an allocation)
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)wgrad_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024);
+        hipError_t e2 = hipFuncSetAttribute((const void*)wgrad_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024);
+        if (e1 != hipSuccess) return (int)e1;
+        if (e2 != hipSuccess) return (int)e2;
+        attr_set = true;
+    }
+    const size_t lds = (size_t)2 * 2 * (128 * tw + 128) * WSLD * sizeof(_Float16);       // 2 buffers x 2 terms
     if (tw == 2)
-        hipLaunchKernelGGL(wgrad_split_kernel<2>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(wgrad_split_kernel<2>, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
     else
-        hipLaunchKernelGGL(wgrad_split_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(wgrad_split_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
     return nf_launch_status();
 }
