@@ -334,6 +334,14 @@ int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, cons
                                       const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
                                       const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,
                                       int64_t B, int in, int out, int relu_in, void* stream);
+/* Backward of nf_affine_fwd (either direction; replaces autograd through transforms.py:540-566 / :323-347): from x,
+ * params (scale recomputed), grad_y[B, x columns] and grad_logabsdet[B] (nullable = 0) to grad_x (written at the D
+ * transformed columns only; with feat_index the caller owns the identity columns) and grad_params[B, 2D] in the
+ * layout of params. */
+int nf_affine_bwd(const float* x, int64_t x_row_stride, const int32_t* feat_index, const float* params,
+                  int64_t param_row_stride, int layout, const float* grad_y, int64_t grad_y_row_stride,
+                  const float* grad_logabsdet, float* grad_x, int64_t grad_x_row_stride, float* grad_params,
+                  int64_t grad_param_row_stride, int64_t B, int D, int inverse, void* stream);
 /* Backward of nf_rqs_fwd(inverse=0, feat_index=NULL): from x, params (recomputed, nothing saved from the
  * forward), grad_y[B,D] and grad_logabsdet[B] to grad_x[B,D] (the spline's direct part) and
  * grad_params[B, D*P] (contiguous rows). */

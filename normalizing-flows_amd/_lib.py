@@ -62,6 +62,9 @@ _SIGNATURES = {
     'nf_affine_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
                                  _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_int,
                                  _c.c_int, _c.c_void_p]),
+    'nf_affine_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
+                                 _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                                 _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_made_rqs_supported': (_c.c_int, [_c.c_int, _c.c_int]),
     'nf_made_rqs_tiles': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_made_rqs_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
@@ -872,6 +875,28 @@ def affine(x, params, layout, inverse=False, feat_index=None, out=None, logabsde
         _check(lib.nf_affine_fwd(xp, xs, _ptr(feat_index), pp, ps, int(layout), yp, ys, logabsdet.data_ptr(),
                                  int(accumulate), B, D, int(inverse), _stream()), 'nf_affine_fwd')
     return out, logabsdet
+
+
+def affine_bwd(x, params, layout, grad_y, grad_lad, inverse=False, feat_index=None, num_features=None):
+    """(grad_x, grad_params) of `affine`.  With `feat_index` (coupling) grad_x starts as a copy of grad_y: the
+    identity columns pass their gradient through and the kernel overwrites the transformed ones."""
+    lib = load()
+    for t, n in ((x, 'inputs'), (params, 'params'), (grad_y, 'grad_y')):
+        _dev(t, n)
+    B = x.shape[0]
+    D = int(num_features if num_features is not None else x.shape[1])
+    xp, xs = _rows(x, 'inputs')
+    pp, ps = _rows(params, 'params')
+    gyp, gys = _rows(grad_y, 'grad_y')
+    gx = grad_y.clone() if feat_index is not None else torch.empty_like(x)
+    gxp, gxs = _rows(gx, 'grad_x')
+    gparams = torch.empty((B, 2 * D), dtype=torch.float32, device=x.device)
+    gpp, gps = _rows(gparams, 'grad_params')
+    gl = None if grad_lad is None else _dev(grad_lad.contiguous(), 'grad_logabsdet')
+    with torch.cuda.device(x.device):
+        _check(lib.nf_affine_bwd(xp, xs, _ptr(feat_index), pp, ps, int(layout), gyp, gys, _ptr(gl), gxp, gxs, gpp, gps,
+                                 B, D, int(inverse), _stream()), 'nf_affine_bwd')
+    return gx, gparams
 
 
 # ------------------------------------------------------------------------------------------------

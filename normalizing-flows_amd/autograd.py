@@ -8,6 +8,7 @@ model.py:233-244).  Here every forward kernel has a hand-written backward kernel
                    backward: grad_x = (grad_y @ (W*mask)) gated by x > 0   (nf_masked_linear_bwd_input)
                              grad_W = mask * grad_y^T @ act_in(x), grad_b  (nf_masked_linear_bwd_weight)
   RqsFn          : (y, logabsdet) = spline(x; params), forward direction
+  AffineFn       : (y, logabsdet) = sigmoid-scale affine(x; params), either direction, AR or coupling layout
                    backward: recompute-from-inputs kernel nf_rqs_bwd -> grad_x, grad_params
 """
 import torch
@@ -93,4 +94,28 @@ class RqsFn(torch.autograd.Function):
             grad_lad = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
         gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
                                    min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2])
+        return gx, gparams, None, None, None, None
+
+
+class AffineFn(torch.autograd.Function):
+    """nf_affine_fwd / nf_affine_bwd.  `feat_index` (int32, coupling) selects the transformed columns; the other
+    columns of the output are the input's, and their gradient passes through."""
+
+    @staticmethod
+    def forward(ctx, x, params, layout, inverse, feat_index, num_features):
+        out = x.clone() if feat_index is not None else torch.empty_like(x)
+        y, lad = _lib.affine(x, params, layout, inverse=inverse, feat_index=feat_index, out=out,
+                             num_features=num_features)
+        ctx.save_for_backward(x, params)
+        ctx.cfg = (layout, inverse, feat_index, num_features)
+        return y, lad
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_lad):
+        x, params = ctx.saved_tensors
+        layout, inverse, feat_index, num_features = ctx.cfg
+        if grad_y is None:
+            grad_y = torch.zeros_like(x)
+        gx, gparams = _lib.affine_bwd(x, params, layout, grad_y.contiguous(), grad_lad, inverse=inverse,
+                                      feat_index=feat_index, num_features=num_features)
         return gx, gparams, None, None, None, None

@@ -276,6 +276,74 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(const AffineArgs a) {
     }
 }
 
+// Backward of affine_kernel: from x, the parameters (scale recomputed), grad_y and grad_logabsdet to grad_x and
+// grad_params (same layout as params).  forward: y = s x + t, lad = sum log s;  inverse: y = (x - t) / s,
+// lad = -sum log s;  s = sigmoid(u + 2) + 1e-3, ds/du = sig (1 - sig).  Pure elementwise: one thread per element.
+struct AffineBwdArgs {
+    const float* x;
+    int64_t x_stride;
+    const int32_t* feat;
+    const float* params;
+    int64_t p_stride;
+    const float* gy;
+    int64_t gy_stride;
+    const float* glad;
+    float* gx;
+    int64_t gx_stride;
+    float* gp;
+    int64_t gp_stride;
+    int64_t B;
+    int D;
+    int layout;
+};
+
+template <bool INV>
+__global__ __launch_bounds__(kThreads) void affine_bwd_kernel(const AffineBwdArgs a) {
+    const int D = a.D;
+    const int64_t total = a.B * D;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t r = e / D;
+        const int d = (int)(e - r * D);
+        const int col = a.feat ? a.feat[d] : d;
+        const float* prow = a.params + r * a.p_stride;
+        float us, shift;
+        if (a.layout == NF_AFFINE_INTERLEAVED) {
+            const float2 v = *reinterpret_cast<const float2*>(prow + 2 * d);
+            us = v.x;
+            shift = v.y;
+        } else {
+            shift = prow[d];
+            us = prow[D + d];
+        }
+        const float sig = 1.0f / (1.0f + expf(-(us + 2.0f)));
+        const float scale = sig + 1e-3f;
+        const float xv = a.x[r * a.x_stride + col];
+        const float gy = a.gy[r * a.gy_stride + col];
+        const float gl = a.glad ? a.glad[r] : 0.0f;
+        float gx, gshift, gscale;
+        if (INV) {
+            const float inv = 1.0f / scale;
+            const float y = (xv - shift) * inv;
+            gx = gy * inv;
+            gshift = -gx;
+            gscale = -(gy * y + gl) * inv;
+        } else {
+            gx = gy * scale;
+            gshift = gy;
+            gscale = gy * xv + gl / scale;
+        }
+        const float gu = gscale * sig * (1.0f - sig);
+        a.gx[r * a.gx_stride + col] = gx;
+        float* grow = a.gp + r * a.gp_stride;
+        if (a.layout == NF_AFFINE_INTERLEAVED) {
+            *reinterpret_cast<float2*>(grow + 2 * d) = make_float2(gu, gshift);
+        } else {
+            grow[d] = gshift;
+            grow[D + d] = gu;
+        }
+    }
+}
+
 int pick_rows_per_block(int D, int64_t B) {
     // ~3k elements per block, whole rows, at most what LDS holds for the logdet buffer
     int r = 3072 / D;
@@ -439,6 +507,33 @@ extern "C" int nf_affine_fwd(const float* x, int64_t x_row_stride, const int32_t
     hipStream_t s = (hipStream_t)stream;
     if (inverse) hipLaunchKernelGGL(affine_kernel<true>, dim3((int)grid), dim3(kThreads), lds, s, a);
     else hipLaunchKernelGGL(affine_kernel<false>, dim3((int)grid), dim3(kThreads), lds, s, a);
+    return nf_launch_status();
+}
+
+extern "C" int nf_affine_bwd(const float* x, int64_t x_row_stride, const int32_t* feat_index, const float* params,
+                             int64_t param_row_stride, int layout, const float* grad_y, int64_t grad_y_row_stride,
+                             const float* grad_logabsdet, float* grad_x, int64_t grad_x_row_stride,
+                             float* grad_params, int64_t grad_param_row_stride, int64_t B, int D, int inverse,
+                             void* stream) {
+    if (B < 0 || D <= 0) return NF_ERR_SHAPE;
+    if (layout != NF_AFFINE_INTERLEAVED && layout != NF_AFFINE_BLOCKED) return NF_ERR_DTYPE;
+    if (B == 0) return NF_OK;
+    if (!x || !params || !grad_y || !grad_x || !grad_params) return NF_ERR_NULL;
+    if (param_row_stride < 2 * (int64_t)D || grad_param_row_stride < 2 * (int64_t)D || x_row_stride < D ||
+        grad_y_row_stride < D || grad_x_row_stride < D)
+        return NF_ERR_LAYOUT;
+    if (layout == NF_AFFINE_INTERLEAVED &&
+        ((((uintptr_t)params) & 7) || (param_row_stride & 1) || (((uintptr_t)grad_params) & 7) || (grad_param_row_stride & 1)))
+        return NF_ERR_LAYOUT;
+    AffineBwdArgs a;
+    a.x = x; a.x_stride = x_row_stride; a.feat = feat_index; a.params = params; a.p_stride = param_row_stride;
+    a.gy = grad_y; a.gy_stride = grad_y_row_stride; a.glad = grad_logabsdet; a.gx = grad_x; a.gx_stride = grad_x_row_stride;
+    a.gp = grad_params; a.gp_stride = grad_param_row_stride; a.B = B; a.D = D; a.layout = layout;
+    const int64_t want = (B * D + kThreads - 1) / kThreads;
+    const int grid = (int)(want < 16384 ? want : 16384);
+    hipStream_t s = (hipStream_t)stream;
+    if (inverse) hipLaunchKernelGGL(affine_bwd_kernel<true>, dim3(grid), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL(affine_bwd_kernel<false>, dim3(grid), dim3(kThreads), 0, s, a);
     return nf_launch_status();
 }
 

@@ -181,6 +181,15 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
     def _elementwise(self, inputs, params, outputs, logabsdet, inverse):
         _lib.affine(inputs, params, _lib.NF_AFFINE_INTERLEAVED, inverse=inverse, out=outputs, logabsdet=logabsdet)
 
+    def _forward_autograd(self, inputs, context):
+        """Training path: conditioner (MaskedLinearFn) and the affine map (AffineFn) over the backward kernels."""
+        from .autograd import AffineFn
+        if context is not None:
+            raise NotImplementedError('context-conditioned training is outside this build')
+        x = inputs.contiguous()
+        params = self.autoregressive_net(x, None)
+        return AffineFn.apply(x, params, _lib.NF_AFFINE_INTERLEAVED, False, None, None)
+
     def inverse(self, inputs, context=None):
         return self._inverse_via_rows(inputs, context, 'affine', None, None,
                                       lambda pi, z, out, hid, ctx: _lib.made_affine_inverse_rows(pi, z, out, hid, ctx=ctx))
@@ -479,10 +488,18 @@ class CouplingTransform(nn.Module):
     def _feat_index(self):
         return self._index32('transform_features')
 
+    def _recording(self, inputs):
+        return torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
+
+    def _run_autograd(self, inputs, context, inverse):
+        raise NotImplementedError('this coupling transform has no backward kernels: call under torch.no_grad()')
+
     def _run(self, inputs, context, inverse):
         _check_2d(inputs, self.features)
         if not inputs.is_contiguous():
             inputs = inputs.contiguous()
+        if self._recording(inputs):
+            return self._run_autograd(inputs, context, inverse)
         identity_split = inputs[:, self.identity_features].contiguous()
         transform_params = self.transform_net(identity_split, context)
         # identity columns pass through; the kernel overwrites the transformed columns in place order
@@ -513,6 +530,15 @@ class AffineCouplingTransform(CouplingTransform):
     def _coupling_elementwise(self, inputs, transform_params, outputs, logabsdet, inverse):
         _lib.affine(inputs, transform_params, _lib.NF_AFFINE_BLOCKED, inverse=inverse, feat_index=self._feat_index(),
                     out=outputs, logabsdet=logabsdet, num_features=self.num_transform_features)
+
+    def _run_autograd(self, inputs, context, inverse):
+        """Training path (either direction): the conditioner through its own autograd route, the affine map and its
+        backward as AffineFn (nf_affine_bwd); identity columns pass values and gradients through."""
+        from .autograd import AffineFn
+        identity_split = inputs[:, self.identity_features].contiguous()
+        transform_params = self.transform_net(identity_split, context)
+        return AffineFn.apply(inputs, transform_params.contiguous(), _lib.NF_AFFINE_BLOCKED, bool(inverse),
+                              self._feat_index(), self.num_transform_features)
 
 
 class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):

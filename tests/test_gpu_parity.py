@@ -883,6 +883,113 @@ def test_split_operand_weight_gradient(nf, B, inp, out, relu_in, masked, bias):
         assert gb is None
 
 
+def _nerr(got, ref):
+    """max |got - ref| / max |ref|."""
+    got, ref = torch.as_tensor(got).double(), torch.as_tensor(ref).double()
+    return (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-300)
+
+
+@pytest.mark.parametrize('layout', ['interleaved', 'blocked', 'blocked_indexed'])
+@pytest.mark.parametrize('inverse', [False, True])
+def test_affine_backward_kernel(nf, layout, inverse):
+    """nf_affine_bwd against torch autograd through the reference's formulas in float64 (transforms.py:540-566
+    autoregressive / :323-347 coupling layouts), both directions; with an index the other columns pass through."""
+    from normalizing_flows_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    B, W = 257, 10
+    x = torch.randn(B, W, generator=g)
+    cols = torch.tensor([1, 3, 4, 8]) if layout == 'blocked_indexed' else torch.arange(W)
+    D = len(cols)
+    params = torch.randn(B, 2 * D, generator=g) * 1.5
+    gy, gl = torch.randn(B, W, generator=g), torch.randn(B, generator=g)
+    x64, p64 = x.double().requires_grad_(True), params.double().requires_grad_(True)
+    if layout == 'interleaved':
+        us, shift = p64.view(B, D, 2)[..., 0], p64.view(B, D, 2)[..., 1]
+    else:
+        shift, us = p64[:, :D], p64[:, D:]
+    scale = torch.sigmoid(us + 2.) + 1e-3
+    xt = x64[:, cols]
+    yt = (xt - shift) / scale if inverse else xt * scale + shift
+    lad = torch.log(scale).sum(1) * (-1 if inverse else 1)
+    y = x64.clone()
+    y[:, cols] = yt
+    ((y * gy.double()).sum() + (lad * gl.double()).sum()).backward()
+    fi = cols.to(torch.int32).cuda() if layout == 'blocked_indexed' else None
+    code = _lib.NF_AFFINE_INTERLEAVED if layout == 'interleaved' else _lib.NF_AFFINE_BLOCKED
+    gx, gp = _lib.affine_bwd(x.cuda(), params.cuda(), code, gy.cuda(), gl.cuda(), inverse=inverse, feat_index=fi,
+                             num_features=D if fi is not None else None)
+    assert _nerr(gx.cpu(), x64.grad) < 1e-5
+    assert ((gp.cpu().double() - p64.grad).abs() <= 1e-5 * p64.grad.abs() + 1e-6).all()
+
+
+def test_affine_ar_training_gradients(nf):
+    """-mean log_prob of a 2-layer masked affine autoregressive flow: parameter and input gradients from
+    MaskedLinearFn + AffineFn against torch autograd through the oracle in float64."""
+    D, H, B = 16, 32, 96
+    sds = [O.seeded_made_state_dict(D, H, 2, seed=40 + j, scale=0.2) for j in range(2)]
+    layers = []
+    for sd in sds:
+        t = nf.MaskedAffineAutoregressiveTransform(features=D, hidden_features=H, num_blocks=2)
+        t.load_state_dict(sd, strict=True)
+        layers.append(t)
+    flow = nf.BaseNeuralSplineFlow(nf.CompositeTransform(layers), nf.StandardNormal([D])).cuda()
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(3))
+    xg = x.cuda().requires_grad_(True)
+    loss = -flow.log_prob(xg).mean()
+    loss.backward()
+    sd64 = [{k: (v.double().requires_grad_(True) if k.endswith(('weight', 'bias')) else
+                 (v.double() if v.is_floating_point() else v)) for k, v in sd.items()} for sd in sds]
+    x64 = x.double().requires_grad_(True)
+    want = -O.flow_log_prob([lambda v, s=s: O.affine_autoregressive_forward(s, v) for s in sd64], x64).mean()
+    want.backward()
+    assert abs(loss.item() - want.item()) < 2e-5 * abs(want.item())
+    assert _nerr(xg.grad.cpu(), x64.grad) < 2e-3
+    named = dict(flow.named_parameters())
+    for j in range(2):
+        for k, v in sd64[j].items():
+            if k.endswith(('weight', 'bias')):
+                got = named['_transform._transforms.%d.%s' % (j, k)].grad.cpu().double()
+                scale = v.grad.abs().max().item() + 1e-12
+                assert (got - v.grad).abs().max().item() / scale < 2e-3, k
+
+
+def test_affine_coupling_training_gradients(nf):
+    """The affine coupling stack of the golden fixture under autograd: forward values unchanged, and the gradient of
+    a scalar of (outputs, logabsdet) w.r.t. the input and every conditioner weight against the oracle in float64;
+    RQ coupling layers, which have no backward kernels, refuse to record instead of dropping gradients."""
+    fx = load_golden('affine_coupling')
+    comp = _coupling_stack(nf, fx, 'affine')
+    sd = golden_state_dict(fx)
+    L = int(fx['n_layers'])
+    x = T(fx['x'])[:64].float()
+    xg = x.cuda().requires_grad_(True)
+    y, ld = comp(xg)
+    assert y.grad_fn is not None and ld.grad_fn is not None
+    assert rel_err(y.detach().cpu(), fx['y64'][:64]) < TOL
+    (y.square().sum() * 0.01 + ld.sum()).backward()
+    sd64 = {k: (v.double().requires_grad_(True) if k.endswith(('weight', 'bias')) else
+                (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    h, tot = x64, 0.
+    for j in range(L):
+        h, l = O.affine_coupling(O.split_state_dict(sd64, j), h)
+        tot = tot + l
+    (h.square().sum() * 0.01 + tot.sum()).backward()
+    assert _nerr(xg.grad.cpu(), x64.grad) < 2e-3
+    named = dict(comp.named_parameters())
+    checked = 0
+    for k, v in sd64.items():
+        if k.endswith(('weight', 'bias')) and v.grad is not None:
+            got = named[k].grad.cpu().double()
+            scale = v.grad.abs().max().item() + 1e-12
+            assert (got - v.grad).abs().max().item() / scale < 2e-3, k
+            checked += 1
+    assert checked >= 6 * L
+    rq = _coupling_stack(nf, load_golden('rq_coupling_linear'), 'linear')
+    with pytest.raises(NotImplementedError):
+        rq(dev(load_golden('rq_coupling_linear')['x'])[:8].requires_grad_(True))
+
+
 def test_short_training_run_lowers_the_loss(nf):
     """A few Adam steps on a 2-D-correlated Gaussian: the loss goes down and weights move only where unmasked."""
     torch.manual_seed(0)
