@@ -77,24 +77,25 @@ class MaskedLinearFn(torch.autograd.Function):
 
 class RqsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, params, num_bins, tails, tail_bound, mins):
-        y, lad, _ = _lib.rqs(x, params, num_bins, tails, tail_bound, min_bin_width=mins[0], min_bin_height=mins[1],
-                             min_derivative=mins[2])
+    def forward(ctx, x, params, num_bins, tails, tail_bound, mins, pre_div=1.0):
+        y, lad, _ = _lib.rqs(x, params, num_bins, tails, tail_bound, pre_div=pre_div, min_bin_width=mins[0],
+                             min_bin_height=mins[1], min_derivative=mins[2])
         ctx.save_for_backward(x, params)
-        ctx.cfg = (num_bins, tails, tail_bound, mins)
+        ctx.cfg = (num_bins, tails, tail_bound, mins, pre_div)
         return y, lad
 
     @staticmethod
     def backward(ctx, grad_y, grad_lad):
         x, params = ctx.saved_tensors
-        num_bins, tails, tail_bound, mins = ctx.cfg
+        num_bins, tails, tail_bound, mins, pre_div = ctx.cfg
         if grad_y is None:
             grad_y = torch.zeros_like(x)
         if grad_lad is None:
             grad_lad = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
         gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
-                                   min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2])
-        return gx, gparams, None, None, None, None
+                                   pre_div=pre_div, min_bin_width=mins[0], min_bin_height=mins[1],
+                                   min_derivative=mins[2])
+        return gx, gparams, None, None, None, None, None
 
 
 class AffineFn(torch.autograd.Function):

@@ -602,6 +602,23 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
             return outputs, logabsdet, bins
         return outputs, logabsdet
 
+    def _run_autograd(self, inputs, context, inverse):
+        """Training path, forward direction: the transformed columns are gathered (torch ops, differentiable), the
+        spline and its backward run as RqsFn (nf_rqs_fwd / nf_rqs_bwd with the coupling pre-divisor), and the result
+        is scattered back beside the identity columns."""
+        from .autograd import RqsFn
+        if inverse:
+            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
+        if self.tails not in (None, 'linear'):
+            raise RuntimeError('{} tails are not implemented.'.format(self.tails))
+        identity_split = inputs[:, self.identity_features].contiguous()
+        params = self.transform_net(identity_split, context).contiguous()
+        xt = inputs.index_select(1, self.transform_features).contiguous()
+        yt, logabsdet = RqsFn.apply(xt, params, self.num_bins, self.tails, self.tail_bound,
+                                    (self.min_bin_width, self.min_bin_height, self.min_derivative),
+                                    float(self._pre_div()))
+        return inputs.index_copy(1, self.transform_features, yt), logabsdet
+
     def _coupling_elementwise(self, inputs, transform_params, outputs, logabsdet, inverse):
         pre_div = self._pre_div()
         if self.tails not in (None, 'linear'):

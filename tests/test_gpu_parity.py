@@ -985,9 +985,44 @@ def test_affine_coupling_training_gradients(nf):
             assert (got - v.grad).abs().max().item() / scale < 2e-3, k
             checked += 1
     assert checked >= 6 * L
-    rq = _coupling_stack(nf, load_golden('rq_coupling_linear'), 'linear')
-    with pytest.raises(NotImplementedError):
-        rq(dev(load_golden('rq_coupling_linear')['x'])[:8].requires_grad_(True))
+    cubic = nf.PiecewiseCubicCouplingTransform(torch.tensor([0., 1.] * 4), lambda i, o: nf.ResidualNet(i, o, 32)).cuda()
+    with pytest.raises(NotImplementedError):                 # no backward kernels: refuses, never drops gradients
+        cubic(torch.rand(8, 8, device='cuda').requires_grad_(True))
+
+
+@pytest.mark.parametrize('tag', ['linear', 'notails'])
+def test_rq_coupling_training_gradients(nf, tag):
+    """The RQ coupling stack of the golden fixtures (cfg-2 shape: ResidualNet conditioner, widths / heights divided by
+    sqrt(hidden)) under autograd: values unchanged, gradients w.r.t. the input and every conditioner weight against
+    torch autograd through the oracle in float64."""
+    fx = load_golden('rq_coupling_' + tag)
+    tails = 'linear' if tag == 'linear' else None
+    comp = _coupling_stack(nf, fx, tails)
+    sd = golden_state_dict(fx)
+    L, K, Tb, Hn = int(fx['n_layers']), int(fx['num_bins']), float(fx['tail_bound']), int(fx['hidden'])
+    x = T(fx['x'])[:48].float()
+    xg = x.cuda().requires_grad_(True)
+    y, ld = comp(xg)
+    assert y.grad_fn is not None and ld.grad_fn is not None
+    assert_close(y.detach(), fx['y64'][:48], fx['y'][:48])
+    (y.square().sum() * 0.01 + ld.sum()).backward()
+    sd64 = {k: (v.double().requires_grad_(True) if k.endswith(('weight', 'bias')) else
+                (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    h, tot = x64, 0.
+    for j in range(L):
+        h, l = O.rq_coupling(O.split_state_dict(sd64, j), h, K, tails, Tb, Hn)
+        tot = tot + l
+    (h.square().sum() * 0.01 + tot.sum()).backward()
+    assert _nerr(xg.grad.cpu(), x64.grad) < 2e-3
+    named = dict(comp.named_parameters())
+    checked = 0
+    for k, v in sd64.items():
+        if k.endswith(('weight', 'bias')) and v.grad is not None:
+            got = named[k].grad.cpu().double()
+            assert (got - v.grad).abs().max().item() / (v.grad.abs().max().item() + 1e-12) < 2e-3, k
+            checked += 1
+    assert checked >= 6 * L
 
 
 def test_short_training_run_lowers_the_loss(nf):
