@@ -184,10 +184,8 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
     def _forward_autograd(self, inputs, context):
         """Training path: conditioner (MaskedLinearFn) and the affine map (AffineFn) over the backward kernels."""
         from .autograd import AffineFn
-        if context is not None:
-            raise NotImplementedError('context-conditioned training is outside this build')
         x = inputs.contiguous()
-        params = self.autoregressive_net(x, None)
+        params = self.autoregressive_net(x, context)
         return AffineFn.apply(x, params, _lib.NF_AFFINE_INTERLEAVED, False, None, None)
 
     def inverse(self, inputs, context=None):
@@ -254,9 +252,7 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         """Training path: conditioner and spline as autograd.Functions over the backward kernels.  The
         parameter tensor is materialised here (the backward needs it); inference uses the fused kernel."""
         from .autograd import RqsFn
-        if context is not None:
-            raise NotImplementedError('context-conditioned training is outside this build')
-        params = self.autoregressive_net(inputs.contiguous(), None)
+        params = self.autoregressive_net(inputs.contiguous(), context)      # context: extra GEMM + GLU gates (torch glue)
         return RqsFn.apply(inputs.contiguous(), params, self.num_bins, self.tails, self.tail_bound,
                            (self.min_bin_width, self.min_bin_height, self.min_derivative))
 

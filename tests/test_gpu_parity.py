@@ -953,6 +953,44 @@ def test_affine_ar_training_gradients(nf):
                 assert (got - v.grad).abs().max().item() / scale < 2e-3, k
 
 
+@pytest.mark.parametrize('kind', ['rq', 'affine'])
+def test_context_conditioned_training_gradients(nf, kind):
+    """Context-conditioned MADE under autograd (context GEMM added to the initial layer, GLU gates in the residual
+    blocks, reference made.py:279-283, :354-355): gradients w.r.t. input, context and every weight against torch
+    autograd through the oracle in float64."""
+    torch.manual_seed(23)
+    D, H, C, B, K, Tb = 16, 32, 8, 80, 4, 3.0
+    if kind == 'rq':
+        t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, context_features=C, num_bins=K,
+                                                                       tails='linear', tail_bound=Tb, num_blocks=2)
+    else:
+        t = nf.MaskedAffineAutoregressiveTransform(D, H, context_features=C, num_blocks=2)
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    sd = {k: v.clone() for k, v in t.state_dict().items()}
+    t = t.cuda()
+    x, ctx = torch.randn(B, D) * 1.2, torch.randn(B, C)
+    xg, cg = x.cuda().requires_grad_(True), ctx.cuda().requires_grad_(True)
+    y, ld = t(xg, cg)
+    (y.square().sum() * 0.01 + ld.sum()).backward()
+    sd64 = {k: (v.double().requires_grad_(True) if k.endswith(('weight', 'bias')) else
+                (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    x64, c64 = x.double().requires_grad_(True), ctx.double().requires_grad_(True)
+    if kind == 'rq':
+        y64, ld64 = O.rq_autoregressive_forward(sd64, x64, K, Tb, context=c64)
+    else:
+        y64, ld64 = O.affine_autoregressive_forward(sd64, x64, context=c64)
+    (y64.square().sum() * 0.01 + ld64.sum()).backward()
+    assert _nerr(y.detach().cpu(), y64.detach()) < 1e-5
+    assert _nerr(xg.grad.cpu(), x64.grad) < 2e-3 and _nerr(cg.grad.cpu(), c64.grad) < 2e-3
+    named = dict(t.named_parameters())
+    for k, v in sd64.items():
+        if k.endswith(('weight', 'bias')):
+            assert v.grad is not None, k
+            assert _nerr(named[k].grad.cpu(), v.grad) < 2e-3, k
+
+
 def test_affine_coupling_training_gradients(nf):
     """The affine coupling stack of the golden fixture under autograd: forward values unchanged, and the gradient of
     a scalar of (outputs, logabsdet) w.r.t. the input and every conditioner weight against the oracle in float64;
