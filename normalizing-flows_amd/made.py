@@ -213,6 +213,17 @@ def _bn_scale_shift(bn):
     return scale.contiguous(), shift.contiguous()
 
 
+def _records(module, inputs):
+    return torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
+def _bn_through_torch(block, inputs):
+    """BatchNorm runs as torch's own op (not folded into the next GEMM's input) in train() mode - batch statistics
+    are a cross-sample reduction and the running statistics get updated, as in the reference - and whenever
+    autograd records; the layers around it stay on the kernels."""
+    return block.training or _records(block, inputs)
+
+
 def _check_activation(activation):
     if activation is not F.relu and activation is not torch.relu:
         raise NotImplementedError('only the reference default activation (F.relu) is fused into the kernels')
@@ -239,6 +250,9 @@ class MaskedFeedforwardBlock(nn.Module):
             raise NotImplementedError()
         if self.training and self.dropout.p > 0:
             raise NotImplementedError('dropout needs train(); this build is inference only')
+        if _records(self, inputs) or (self.batch_norm is not None and self.training):
+            temps = inputs if self.batch_norm is None else self.batch_norm(inputs)
+            return torch.relu(self.linear.fused(temps))
         sc, sh = _bn_scale_shift(self.batch_norm) if self.batch_norm is not None else (None, None)
         return self.linear.fused(inputs, in_scale=sc, in_shift=sh, relu_out=True)
 
@@ -275,10 +289,14 @@ class MaskedResidualBlock(nn.Module):
         if self.training and self.dropout.p > 0:
             raise NotImplementedError('dropout needs train(); this build is inference only')
         s0 = h0 = s1 = h1 = None
-        if self.use_batch_norm:
-            s0, h0 = _bn_scale_shift(self.batch_norm_layers[0])
-            s1, h1 = _bn_scale_shift(self.batch_norm_layers[1])
-        temps = self.linear_layers[0].fused(inputs, in_scale=s0, in_shift=h0, relu_in=True)
+        if self.use_batch_norm and _bn_through_torch(self, inputs):
+            temps = self.linear_layers[0].fused(self.batch_norm_layers[0](inputs), relu_in=True)
+            temps = self.batch_norm_layers[1](temps)
+        else:
+            if self.use_batch_norm:
+                s0, h0 = _bn_scale_shift(self.batch_norm_layers[0])
+                s1, h1 = _bn_scale_shift(self.batch_norm_layers[1])
+            temps = self.linear_layers[0].fused(inputs, in_scale=s0, in_shift=h0, relu_in=True)
         if context is None:
             return self.linear_layers[1].fused(temps, in_scale=s1, in_shift=h1, relu_in=True, residual=inputs)
         temps = self.linear_layers[1].fused(temps, in_scale=s1, in_shift=h1, relu_in=True)

@@ -9,7 +9,7 @@ from torch import nn
 from torch.nn import functional as F, init
 
 from . import _lib
-from .made import DenseLinear, _bn_scale_shift, _check_activation
+from .made import DenseLinear, _bn_scale_shift, _bn_through_torch, _check_activation
 
 
 class ResidualBlock(nn.Module):
@@ -35,10 +35,14 @@ class ResidualBlock(nn.Module):
         if self.training and self.dropout.p > 0:
             raise NotImplementedError('dropout needs train(); this build is inference only')
         s0 = h0 = s1 = h1 = None
-        if self.use_batch_norm:
-            s0, h0 = _bn_scale_shift(self.batch_norm_layers[0])
-            s1, h1 = _bn_scale_shift(self.batch_norm_layers[1])
-        temps = self.linear_layers[0].fused(inputs, in_scale=s0, in_shift=h0, relu_in=True)
+        if self.use_batch_norm and _bn_through_torch(self, inputs):
+            temps = self.linear_layers[0].fused(self.batch_norm_layers[0](inputs), relu_in=True)
+            temps = self.batch_norm_layers[1](temps)
+        else:
+            if self.use_batch_norm:
+                s0, h0 = _bn_scale_shift(self.batch_norm_layers[0])
+                s1, h1 = _bn_scale_shift(self.batch_norm_layers[1])
+            temps = self.linear_layers[0].fused(inputs, in_scale=s0, in_shift=h0, relu_in=True)
         if context is None:
             return self.linear_layers[1].fused(temps, in_scale=s1, in_shift=h1, relu_in=True, residual=inputs)
         temps = self.linear_layers[1].fused(temps, in_scale=s1, in_shift=h1, relu_in=True)

@@ -83,8 +83,8 @@ class AutoregressiveTransform(nn.Module):
         B = inputs.shape[0]
         outputs = torch.empty_like(inputs)
         logabsdet = torch.empty(B, dtype=inputs.dtype, device=inputs.device)
-        if B <= CHUNK_ROWS:
-            # one launch group: no slicing, so the tensors keep what the kernels attached to them (the
+        if B <= CHUNK_ROWS or any(isinstance(m, nn.BatchNorm1d) and m.training for m in self.modules()):
+            # one launch group (always with BatchNorm in train() mode: its statistics are the whole batch's): no slicing, so the tensors keep what the kernels attached to them (the
             # split-operand kernels hand max |y| to the next layer's first GEMM that way)
             self._transform_rows(inputs, inputs, context, outputs, logabsdet, inverse=False)
             return outputs, logabsdet

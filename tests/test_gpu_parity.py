@@ -991,6 +991,91 @@ def test_context_conditioned_training_gradients(nf, kind):
             assert _nerr(named[k].grad.cpu(), v.grad) < 2e-3, k
 
 
+def test_batch_norm_in_train_mode(nf):
+    """use_batch_norm=True in train() mode (the reference factory's default blocks, made.py:232-236, :268-284):
+    BatchNorm takes batch statistics (torch's op between the kernels' layers) and updates its running statistics;
+    outputs, running statistics and gradients against the same network written with torch ops in float64."""
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    D, H, B, K, Tb = 16, 32, 128, 4, 3.0
+    t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, num_bins=K, tails='linear', tail_bound=Tb,
+                                                                   num_blocks=2, use_batch_norm=True)
+    with torch.no_grad():
+        for n_, p in t.named_parameters():
+            if 'batch_norm' in n_:
+                p.add_(torch.randn_like(p) * 0.2)
+            else:
+                p.mul_(1.5)
+    sd = {k: v.clone() for k, v in t.state_dict().items()}
+    t = t.cuda().train()
+    x = torch.randn(B, D) * 1.2
+    xg = x.cuda().requires_grad_(True)
+    y, ld = t(xg)
+    (y.square().sum() * 0.01 + ld.sum()).backward()
+
+    sd64 = {k: (v.double().requires_grad_(True) if k.endswith(('weight', 'bias')) else
+                (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    pre = 'autoregressive_net.'
+    h = O._masked_linear(sd64, pre + 'initial_layer', x64)
+    stats = {}
+    for i in range(2):
+        b = pre + 'blocks.%d.' % i
+        tmp = h
+        for j in range(2):
+            name = b + 'batch_norm_layers.%d' % j
+            stats[name] = (tmp.mean(0).detach(), tmp.var(0, unbiased=True).detach())
+            tmp = F.batch_norm(tmp, None, None, sd64[name + '.weight'], sd64[name + '.bias'], True, 0.1, 1e-3)
+            tmp = O._masked_linear(sd64, b + 'linear_layers.%d' % j, torch.relu(tmp))
+        h = h + tmp
+    params = O._masked_linear(sd64, pre + 'final_layer', h)
+    y64, ld64 = O._rq_ar_elementwise(x64, params, K, Tb, False, (1e-3, 1e-3, 1e-3))
+    (y64.square().sum() * 0.01 + ld64.sum()).backward()
+    assert _nerr(y.detach().cpu(), y64.detach()) < 2e-5 and _nerr(ld.detach().cpu(), ld64.detach()) < 2e-5
+    assert _nerr(xg.grad.cpu(), x64.grad) < 2e-3
+    named = dict(t.named_parameters())
+    for k, v in sd64.items():
+        if k.endswith(('weight', 'bias')):
+            # (a bias in front of a train-mode BatchNorm has zero gradient: absolute floor)
+            diff = (named[k].grad.cpu().double() - v.grad).abs().max().item()
+            assert diff < 3e-3 * v.grad.abs().max().item() + 1e-6, k
+    now = t.state_dict()
+    for name, (mean, var) in stats.items():           # momentum 0.1 from (0, 1)
+        assert _nerr(now[name + '.running_mean'].cpu(), 0.1 * mean) < 1e-4
+        assert _nerr(now[name + '.running_var'].cpu(), 0.9 + 0.1 * var) < 1e-4
+    # eval() afterwards: the folded scale / shift path with the updated statistics, same as torch's eval BatchNorm
+    t.eval()
+    with torch.no_grad():
+        ye, lde = t(x.cuda())
+    sde = {k: (v.double().cpu() if v.is_floating_point() else v.cpu()) for k, v in now.items()}
+    yo, ldo = O.rq_autoregressive_forward(sde, x.double(), K, Tb)
+    assert _nerr(ye.cpu(), yo) < 2e-5 and _nerr(lde.cpu(), ldo) < 2e-5
+
+
+def test_feedforward_blocks_train(nf):
+    """use_residual_blocks=False (MaskedFeedforwardBlock, made.py:155-207) under autograd: masked linear through
+    MaskedLinearFn, ReLU as torch glue; gradients against the oracle in float64."""
+    torch.manual_seed(9)
+    D, H, B = 16, 32, 64
+    t = nf.MaskedAffineAutoregressiveTransform(D, H, num_blocks=2, use_residual_blocks=False)
+    sd = {k: v.clone() for k, v in t.state_dict().items()}
+    t = t.cuda()
+    x = torch.randn(B, D)
+    xg = x.cuda().requires_grad_(True)
+    y, ld = t(xg)
+    (y.square().sum() * 0.01 + ld.sum()).backward()
+    sd64 = {k: (v.double().requires_grad_(True) if k.endswith(('weight', 'bias')) else
+                (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    y64, ld64 = O.affine_autoregressive_forward(sd64, x64)
+    (y64.square().sum() * 0.01 + ld64.sum()).backward()
+    assert _nerr(y.detach().cpu(), y64.detach()) < 1e-5 and _nerr(xg.grad.cpu(), x64.grad) < 2e-3
+    named = dict(t.named_parameters())
+    for k, v in sd64.items():
+        if k.endswith(('weight', 'bias')):
+            assert _nerr(named[k].grad.cpu(), v.grad) < 2e-3, k
+
+
 def test_affine_coupling_training_gradients(nf):
     """The affine coupling stack of the golden fixture under autograd: forward values unchanged, and the gradient of
     a scalar of (outputs, logabsdet) w.r.t. the input and every conditioner weight against the oracle in float64;
