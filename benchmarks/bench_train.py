@@ -24,7 +24,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--layers', type=int, default=5)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16x2', 'bf16x3'],
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16x2', 'bf16x3', 'bf16'],
                     help='matrix mode of the forward and input-gradient GEMMs (weight gradients: fp32 MFMA)')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -28,6 +28,11 @@ def _f16x2_mode():
     return made.get_matmul_dtype() == 'f16x2'
 
 
+def _bf16_mode():
+    from . import made
+    return made.get_matmul_dtype() == 'bf16'
+
+
 class MaskedLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, layer, relu_in):
@@ -64,7 +69,12 @@ class MaskedLinearFn(torch.autograd.Function):
             else:
                 gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if ctx.relu_in else None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            if split_y and ctx.x_max is not None and _f16x2_mode():
+            if _bf16_mode() and _lib.split_gemm_supported(grad_y, layer.out_features):
+                # bf16 mode has no bf16 weight-gradient kernel: the two-term fp16 one (more exact, fp16 MFMA rate)
+                gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
+                                                             layer._packed_linear().ktab, ctx.relu_in,
+                                                             want_bias=ctx.has_bias)
+            elif split_y and ctx.x_max is not None and _f16x2_mode():
                 gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
                                                              layer._packed_linear().ktab, ctx.relu_in,
                                                              want_bias=ctx.has_bias, x_max=ctx.x_max, grad_y_max=gy_max)

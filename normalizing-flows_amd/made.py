@@ -125,11 +125,12 @@ class _PackedMixin:
         """Transposed pack for the input-gradient GEMM, cached like the forward pack."""
         mask = getattr(self, 'mask', None)
         mkey = None if mask is None else (mask._version, mask.data_ptr())
-        key = (self.weight._version, self.weight.data_ptr(), self.weight.device, mkey)
+        dtype = _GEMM_DTYPE[get_matmul_dtype()]         # bf16 mode: the input-gradient GEMM runs on bf16 MFMA too
+        key = (self.weight._version, self.weight.data_ptr(), self.weight.device, dtype, mkey)
         cached = getattr(self, '_pack_t_cache', None)
         if cached is None or cached[0] != key:
             same_mask = cached is not None and cached[0][-1] == mkey
-            plt = _lib.PackedLinearT(self.weight, mask, _lib.NF_DTYPE_F32, reuse=cached[1] if same_mask else None)
+            plt = _lib.PackedLinearT(self.weight, mask, dtype, reuse=cached[1] if same_mask else None)
             object.__setattr__(self, '_pack_t_cache', (key, plt))
             cached = self._pack_t_cache
         return cached[1]
