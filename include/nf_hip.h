@@ -217,7 +217,9 @@ int nf_linear_split_repack(const float* W, const float* mask, const float* bias,
 /* slot <- bit pattern of the largest finite |x[b, c]| (cols % 4 == 0, 16-byte aligned rows). */
 int nf_maxabs(const float* x, int64_t x_row_stride, int64_t B, int cols, uint32_t* slot, void* stream);
 /* y = [relu](x) @ (W*mask)^T + bias (+ residual) [relu].  x_max: slot holding max |x| (nf_maxabs, or the y_max of
- * the launch that produced x; required for NF_DTYPE_F16X2); y_max (nullable) receives max |y|.  in % 8 == 0. */
+ * the launch that produced x; required for NF_DTYPE_F16X2); y_max (nullable) receives max |y|.  in % 8 == 0.
+ * relu_out == 2: `residual` is a gate instead - y is zeroed where residual <= 0 (the ReLU derivative when this
+ * launch is the input-gradient GEMM of a layer that applied ReLU to its input). */
 int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, const uint32_t* x_max, const void* packed_w,
                                const int32_t* ktab, const float* bias_packed, const float* residual,
                                int64_t res_row_stride, float* y, int64_t y_row_stride, uint32_t* y_max, int64_t B,

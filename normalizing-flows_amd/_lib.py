@@ -274,7 +274,7 @@ def maxabs(x):
     return slot
 
 
-def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, out=None, x_max=None):
+def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, out=None, x_max=None, gate=None):
     """Split-operand hidden-layer GEMM.  The result carries `_nf_max` (slot with max |out|) so that a following
     split-operand launch needs no pass over it; x's own slot (`x_max`, else x._nf_max) is used when present, else
     computed here."""
@@ -288,6 +288,11 @@ def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, ou
         out = torch.empty((B, pls.out), dtype=torch.float32, device=x.device)
     yp, ys = _rows(out, 'out')
     rp, rs = (None, 0) if residual is None else _rows(_dev(residual, 'residual'), 'residual')
+    if gate is not None:                      # y zeroed where gate <= 0 (ReLU derivative of an input-gradient GEMM)
+        if residual is not None or relu_out:
+            raise ValueError('gate excludes residual / relu_out')
+        rp, rs = _rows(_dev(gate, 'gate'), 'gate')
+        relu_out = 2
     if x_max is None:
         x_max = getattr(x, '_nf_max', None)
     if x_max is None and pls.dtype == NF_DTYPE_F16X2:

@@ -850,8 +850,13 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
                     const int64_t row = m0 + i * 32 + (qh + q) * 4 + (lane >> 4);
                     float4 v = *reinterpret_cast<const float4*>(ot + ((qh + q) * 4 + (lane >> 4)) * XOT + (lane & 15) * 4);
                     if (SP::SCALED) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
-                    v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w;
-                    if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (g.relu_out == 2) {          // `residual` is a gate: the ReLU derivative of an input-gradient GEMM
+                        v.x = rv[q].x > 0.f ? v.x : 0.f; v.y = rv[q].y > 0.f ? v.y : 0.f;
+                        v.z = rv[q].z > 0.f ? v.z : 0.f; v.w = rv[q].w > 0.f ? v.w : 0.f;
+                    } else {
+                        v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w;
+                        if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    }
                     if (row < g.M && c0 < g.N) {
                         *reinterpret_cast<float4*>(g.y + row * g.ldy + c0) = v;
                         const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
@@ -873,8 +878,11 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
                     const int64_t row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < g.M) {
                         float v = SP::SCALED ? acc[i][j][r] * oscale : acc[i][j][r];
-                        if (g.residual) v += g.residual[row * g.ldr + col];
-                        if (g.relu_out) v = fmaxf(v, 0.f);
+                        if (g.relu_out == 2) v = g.residual[row * g.ldr + col] > 0.f ? v : 0.f;
+                        else {
+                            if (g.residual) v += g.residual[row * g.ldr + col];
+                            if (g.relu_out) v = fmaxf(v, 0.f);
+                        }
                         g.y[row * g.ldy + col] = v;
                         const float a = fabsf(v);
                         vmax = fmaxf(vmax, a < INFINITY ? a : 0.f);
@@ -1613,6 +1621,7 @@ extern "C" int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, 
     }
     if (B == 0) return NF_OK;
     if (!x || !packed_w || !ktab || !bias_packed || !y || (dtype == NF_DTYPE_F16X2 && !x_max)) return NF_ERR_NULL;
+    if (relu_out < 0 || relu_out > 2 || (relu_out == 2 && !residual)) return NF_ERR_NULL;
     if (x_row_stride < in || y_row_stride < out || (residual && res_row_stride < out)) return NF_ERR_LAYOUT;
     if (in % 8 != 0 || x_row_stride % 4 != 0 || ((uintptr_t)x & 15) != 0) return NF_ERR_LAYOUT;
     FusedArgs g = {};
