@@ -1650,7 +1650,7 @@ extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_s
     if (B == 0) return NF_OK;
     if (!x || !grad_y || !grad_w || !x_max || !grad_y_max) return NF_ERR_NULL;
     if (x_row_stride < in || grad_y_row_stride < out) return NF_ERR_LAYOUT;
-    if (x_row_stride > (1 << 24) || grad_y_row_stride > (1 << 24)) return NF_ERR_LAYOUT;     // 32-bit offsets within a chunk
+    if (x_row_stride > (1 << 23) || grad_y_row_stride > (1 << 23)) return NF_ERR_LAYOUT;     // 31-bit byte offsets within a chunk
     WgradSplitArgs g;
     g.x = x; g.ldx = x_row_stride; g.gy = grad_y; g.ldgy = grad_y_row_stride; g.x_max = (const unsigned*)x_max;
     g.gy_max = (const unsigned*)grad_y_max; g.mask = mask; g.ktab = ktab; g.gw = grad_w; g.gb = grad_b; g.M = B; g.out = out; g.in = in;
