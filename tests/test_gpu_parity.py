@@ -1148,6 +1148,26 @@ def test_rq_coupling_training_gradients(nf, tag):
     assert checked >= 6 * L
 
 
+@pytest.mark.parametrize('out', [96, 50])
+def test_split_gemm_gate_epilogue(nf, out):
+    """relu_out = 2 of nf_masked_linear_split_fwd: the output is zeroed where the gate is <= 0, bit-identical to the
+    ungated launch times (gate > 0); 16-byte and 4-byte epilogues (out % 4 != 0), and the max slot covers the gated values."""
+    from normalizing_flows_amd import _lib
+    g = torch.Generator().manual_seed(out)
+    B, inp = 300, 64
+    w, x = torch.randn(out, inp, generator=g).cuda(), torch.randn(B, inp, generator=g).cuda()
+    gate = torch.randn(B, out, generator=g).cuda()
+    pls = _lib.PackedLinearSplit(w, None, None, _lib.NF_DTYPE_F16X2)
+    plain = _lib.masked_linear_split(x, pls)
+    gated = _lib.masked_linear_split(x, pls, gate=gate)
+    want = plain * (gate > 0)
+    assert torch.equal(gated, want)
+    slot = gated._nf_max.view(torch.float32).item()
+    assert slot == want.abs().max().item()
+    with pytest.raises(ValueError):
+        _lib.masked_linear_split(x, pls, gate=gate, relu_out=True)
+
+
 def test_training_gradients_in_bf16_mode(nf):
     """bf16 MADE training (SURVEY cfg-5): forward and input-gradient GEMMs on bf16 MFMA, weight gradients on the
     two-term fp16 kernel; loss within 2e-2 and every gradient tensor within 0.2 (l2) of the fp32 mode of the same model."""
