@@ -7,8 +7,10 @@ submodule / buffer names (so a reference ``state_dict`` loads with ``strict=True
 tiles (nf_made_pack) and every layer runs as one fused MFMA kernel (nf_masked_linear_fwd) with the
 ReLU / eval-BatchNorm prologue and the bias / skip epilogue inside it.
 
-Scope of this build: inference (``eval()``; dropout off, BatchNorm running statistics), ReLU
-activation (the reference default).  Anything else raises instead of silently taking another path.
+Scope of this build: ReLU activation (the reference default).  Inference (``eval()`` / no-grad) runs entirely on
+the fused kernels; under autograd the GEMMs run as ``MaskedLinearFn`` (forward / input-gradient / weight-gradient
+kernels) and BatchNorm (train() statistics), dropout and the context GLU gate are torch ops between them.
+Anything else raises instead of silently taking another path.
 """
 import torch
 from torch import nn
@@ -60,7 +62,7 @@ def _require_inference(module, activation=None):
     if _training(module):
         raise NotImplementedError(
             'this configuration has no backward kernel: call under torch.no_grad() (trainable today: '
-            'residual-block MADE without BatchNorm / context, RQ-spline autoregressive transform)')
+            'RQ-spline / affine autoregressive and coupling transforms, forward direction)')
 
 
 class _PackedMixin:
@@ -249,11 +251,10 @@ class MaskedFeedforwardBlock(nn.Module):
     def forward(self, inputs, context=None):
         if context is not None:
             raise NotImplementedError()
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError('dropout needs train(); this build is inference only')
-        if _records(self, inputs) or (self.batch_norm is not None and self.training):
+        dropping = self.training and self.dropout.p > 0
+        if dropping or _records(self, inputs) or (self.batch_norm is not None and self.training):
             temps = inputs if self.batch_norm is None else self.batch_norm(inputs)
-            return torch.relu(self.linear.fused(temps))
+            return self.dropout(torch.relu(self.linear.fused(temps)))
         sc, sh = _bn_scale_shift(self.batch_norm) if self.batch_norm is not None else (None, None)
         return self.linear.fused(inputs, in_scale=sc, in_shift=sh, relu_out=True)
 
@@ -287,9 +288,15 @@ class MaskedResidualBlock(nn.Module):
             init.uniform_(self.linear_layers[-1].bias, a=-1e-3, b=1e-3)
 
     def forward(self, inputs, context=None):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError('dropout needs train(); this build is inference only')
         s0 = h0 = s1 = h1 = None
+        if self.training and self.dropout.p > 0:
+            # drop(act(BN1?(.))) in train() mode (made.py:275-278): torch's dropout between the two layers
+            bn = self.batch_norm_layers if self.use_batch_norm else (lambda t: t, lambda t: t)
+            temps = bn[1](self.linear_layers[0].fused(bn[0](inputs), relu_in=True))
+            temps = self.dropout(torch.relu(temps))
+            if context is None:
+                return self.linear_layers[1].fused(temps, residual=inputs)
+            return inputs + self.linear_layers[1].fused(temps) * torch.sigmoid(self.context_layer(context))
         if self.use_batch_norm and _bn_through_torch(self, inputs):
             temps = self.linear_layers[0].fused(self.batch_norm_layers[0](inputs), relu_in=True)
             temps = self.batch_norm_layers[1](temps)
@@ -345,6 +352,9 @@ class MADE(nn.Module):
         """The hidden stack as a list of fused-layer steps over named buffers, for evaluating it
         tile window by tile window: (layer, src, dst, residual or None, relu_in, relu_out, bn or None).
         Buffer 'x' is the network input; the last dst is the hidden state the final layer reads."""
+        if any(b.training and b.dropout.p > 0 for b in self.blocks):
+            raise NotImplementedError('dropout is active (train() mode): the inverse kernels evaluate the network '
+                                      'without it - call eval()')
         steps = [(self.initial_layer, 'x', 'h0', None, False, False, None)]
         cur = 'h0'
         for i, block in enumerate(self.blocks):

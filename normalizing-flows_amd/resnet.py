@@ -32,9 +32,15 @@ class ResidualBlock(nn.Module):
             init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
 
     def forward(self, inputs, context=None):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError('dropout needs train(); this build is inference only')
         s0 = h0 = s1 = h1 = None
+        if self.training and self.dropout.p > 0:
+            # drop(act(BN1?(.))) in train() mode (resnet.py:44-50): torch's dropout between the two layers
+            bn = self.batch_norm_layers if self.use_batch_norm else (lambda t: t, lambda t: t)
+            temps = bn[1](self.linear_layers[0].fused(bn[0](inputs), relu_in=True))
+            temps = self.dropout(torch.relu(temps))
+            if context is None:
+                return self.linear_layers[1].fused(temps, residual=inputs)
+            return inputs + self.linear_layers[1].fused(temps) * torch.sigmoid(self.context_layer(context))
         if self.use_batch_norm and _bn_through_torch(self, inputs):
             temps = self.linear_layers[0].fused(self.batch_norm_layers[0](inputs), relu_in=True)
             temps = self.batch_norm_layers[1](temps)
@@ -101,7 +107,7 @@ class ResidualNet(nn.Module):
         """One launch for initial layer + blocks (nf_resnet_hidden_fwd): inference, no context, ReLU,
         hidden width a multiple of 32 up to 128."""
         return (context is None and self.context_features is None and not self.records_grad(inputs)
-                and not any(b.use_batch_norm and b.training for b in self.blocks)
+                and not any(b.training and (b.use_batch_norm or b.dropout.p > 0) for b in self.blocks)
                 and all(b.activation in (F.relu, torch.relu) for b in self.blocks)
                 and _lib.resnet_hidden_supported(self.initial_layer.in_features, self.hidden_features))
 

@@ -1052,6 +1052,59 @@ def test_batch_norm_in_train_mode(nf):
     assert _nerr(ye.cpu(), yo) < 2e-5 and _nerr(lde.cpu(), ldo) < 2e-5
 
 
+def test_dropout_in_train_mode(nf):
+    """dropout_probability > 0 in train() mode (made.py:275-278): torch's dropout sits between the two layers of a
+    block.  The masks it drew are read back through forward hooks and the same network is evaluated with them in
+    float64: values and gradients agree; in eval() the layer is the dropout-free one; the inverse refuses train()."""
+    torch.manual_seed(31)
+    D, H, B = 16, 32, 64
+    t = nf.MaskedAffineAutoregressiveTransform(D, H, num_blocks=2, dropout_probability=0.3)
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    sd = {k: v.clone() for k, v in t.state_dict().items()}
+    t = t.cuda().train()
+    masks = []
+    # kept entries are scaled by 1 / (1 - p); where the ReLU output was already 0 the mask does not matter
+    hooks = [b.dropout.register_forward_hook(lambda m, i, o: masks.append((o != 0).double().cpu() / 0.7))
+             for b in t.autoregressive_net.blocks]
+    x = torch.randn(B, D)
+    xg = x.cuda().requires_grad_(True)
+    y, ld = t(xg)
+    (y.square().sum() * 0.01 + ld.sum()).backward()
+    for h in hooks:
+        h.remove()
+    assert len(masks) == 2 and all(0.1 < (m == 0).double().mean() for m in masks)
+    sd64 = {k: (v.double().requires_grad_(True) if k.endswith(('weight', 'bias')) else
+                (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    pre = 'autoregressive_net.'
+    h = O._masked_linear(sd64, pre + 'initial_layer', x64)
+    for i in range(2):
+        b = pre + 'blocks.%d.' % i
+        tmp = O._masked_linear(sd64, b + 'linear_layers.0', torch.relu(h))
+        tmp = torch.relu(tmp) * masks[i]
+        h = h + O._masked_linear(sd64, b + 'linear_layers.1', tmp)
+    params = O._masked_linear(sd64, pre + 'final_layer', h)
+    scale, shift = O._affine_scale_shift_interleaved(params, D)
+    y64, ld64 = scale * x64 + shift, torch.log(scale).sum(1)
+    (y64.square().sum() * 0.01 + ld64.sum()).backward()
+    assert _nerr(y.detach().cpu(), y64.detach()) < 1e-5 and _nerr(ld.detach().cpu(), ld64.detach()) < 1e-5
+    assert _nerr(xg.grad.cpu(), x64.grad) < 2e-3
+    named = dict(t.named_parameters())
+    for k, v in sd64.items():
+        if k.endswith(('weight', 'bias')):
+            assert _nerr(named[k].grad.cpu(), v.grad) < 2e-3, k
+    with torch.no_grad():
+        with pytest.raises(NotImplementedError):
+            t.inverse(x.cuda())
+        t.eval()
+        ye, _ = t(x.cuda())
+        yo, _ = O.affine_autoregressive_forward({k: (v.double() if v.is_floating_point() else v)
+                                                 for k, v in sd.items()}, x.double())
+        assert _nerr(ye.cpu(), yo) < 1e-5
+
+
 def test_feedforward_blocks_train(nf):
     """use_residual_blocks=False (MaskedFeedforwardBlock, made.py:155-207) under autograd: masked linear through
     MaskedLinearFn, ReLU as torch glue; gradients against the oracle in float64."""
