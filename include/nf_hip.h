@@ -214,7 +214,8 @@ int nf_linear_split_pack(const float* W, const float* mask, const float* bias, i
  * rewritten, the K-range table in ktab (a scan of the whole mask) is kept.  Training repacks every step. */
 int nf_linear_split_repack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
                          void* packed, int32_t* ktab, float* bias_packed, void* stream);
-/* slot <- bit pattern of the largest finite |x[b, c]| (cols % 4 == 0, 16-byte aligned rows). */
+/* slot <- bit pattern of the largest finite |x[b, c]| (any width / alignment; 16-byte loads when cols % 4 == 0 and
+ * the rows are 16-byte aligned). */
 int nf_maxabs(const float* x, int64_t x_row_stride, int64_t B, int cols, uint32_t* slot, void* stream);
 /* y = [relu](x) @ (W*mask)^T + bias (+ residual) [relu].  x_max: slot holding max |x| (nf_maxabs, or the y_max of
  * the launch that produced x; required for NF_DTYPE_F16X2); y_max (nullable) receives max |y|.  in % 8 == 0.
@@ -324,7 +325,8 @@ int nf_masked_linear_bwd_input(const float* grad_y, int64_t grad_y_row_stride, c
 /* grad_w[out,in] += mask * (grad_y^T @ act(x)); grad_b[out] += column sums of grad_y (either may be NULL).
  * ACCUMULATING: zero the buffers before the first call.  fp32 atomics are used when the batch is split
  * over workgroups (last bits depend on arrival order).  ktab (nullable) = the layer's forward K-tile table.
- * Requires in % 4 == 0, out % 4 == 0 and 16-byte aligned rows. */
+ * Any widths and alignment: 16-byte operand loads when in % 4 == 0, out % 4 == 0 and both row sets are 16-byte
+ * aligned, bounded scalar loads otherwise (D = 2, D = 6 with K = 4, odd identity halves ...). */
 int nf_masked_linear_bwd_weight(const float* x, int64_t x_row_stride, const float* grad_y,
                                 int64_t grad_y_row_stride, const float* mask, const int32_t* ktab,
                                 float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,

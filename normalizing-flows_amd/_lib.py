@@ -263,6 +263,22 @@ def split_gemm_supported(x, in_features):
             and x.data_ptr() % 16 == 0)
 
 
+def tag_max(t, slot):
+    """Attach `slot` (max |t| as the producing kernel left it) to t.  The tag names the storage and its version, so
+    an in-place write to t afterwards (y.mul_(), normal_() into the same object ...) makes it stale instead of
+    handing a wrong fp16 operand scale to the next split-operand launch."""
+    t._nf_max = None if slot is None else (slot, t._version, t.data_ptr())
+
+
+def tagged_max(t):
+    """The slot attached by tag_max, or None when there is none or t was written since."""
+    tag = getattr(t, '_nf_max', None)
+    if tag is None:
+        return None
+    slot, version, ptr = tag
+    return slot if (t._version == version and t.data_ptr() == ptr) else None
+
+
 def maxabs(x):
     """int32[1] slot holding the bit pattern of the largest finite |x| (operand scale of the f16x2 kernels)."""
     lib = load()
@@ -275,9 +291,9 @@ def maxabs(x):
 
 
 def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, out=None, x_max=None, gate=None):
-    """Split-operand hidden-layer GEMM.  The result carries `_nf_max` (slot with max |out|) so that a following
-    split-operand launch needs no pass over it; x's own slot (`x_max`, else x._nf_max) is used when present, else
-    computed here."""
+    """Split-operand hidden-layer GEMM.  The result is tagged (tag_max) with the slot holding max |out| so that a
+    following split-operand launch needs no pass over it; x's own slot (`x_max`, else its valid tag) is used when
+    present, else computed here."""
     lib = load()
     _dev(x, 'x')
     xp, xs = _rows(x, 'x')
@@ -294,7 +310,7 @@ def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, ou
         rp, rs = _rows(_dev(gate, 'gate'), 'gate')
         relu_out = 2
     if x_max is None:
-        x_max = getattr(x, '_nf_max', None)
+        x_max = tagged_max(x)
     if x_max is None and pls.dtype == NF_DTYPE_F16X2:
         x_max = maxabs(x)
     y_max = torch.empty(1, dtype=torch.int32, device=x.device)
@@ -306,7 +322,7 @@ def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, ou
     with torch.cuda.device(x.device):
         code = launch() if _timer is None else _timer.record(('masked_linear', pls.inp, pls.out, B), launch)
         _check(code, 'nf_masked_linear_split_fwd')
-    out._nf_max = y_max
+    tag_max(out, y_max)
     return out
 
 
@@ -484,7 +500,7 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
     # a split-operand producer left max |h| beside the tensor: whole-layer launches can skip their own pass
     whole_split = (tiles is None and feat_limit is None and feat_index is None
                    and pf.dtype in (NF_DTYPE_F16X2, NF_DTYPE_BF16X3))
-    h_max = getattr(h, '_nf_max', None) if whole_split else None
+    h_max = tagged_max(h) if whole_split else None
     y_max = torch.empty(1, dtype=torch.int32, device=x.device) if whole_split else None
 
     def launch():
@@ -511,7 +527,7 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
     with torch.cuda.device(x.device):
         code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * (3 * pf.K - 1), B), launch)
         _check(code, 'nf_made_rqs_fwd')
-    out._nf_max = y_max                 # (None outside the split-operand whole-layer launches)
+    tag_max(out, y_max)                 # (None outside the split-operand whole-layer launches)
     return out, logabsdet, bins
 
 
@@ -758,7 +774,7 @@ def masked_linear(x, pl, residual=None, in_scale=None, in_shift=None, relu_in=Fa
         out = torch.empty((B, pl.out), dtype=torch.float32, device=x.device)
     yp, ys = _rows(out, 'out')
     if getattr(out, '_nf_max', None) is not None:
-        out._nf_max = None              # a split-operand launch's max |out| no longer describes this buffer
+        tag_max(out, None)              # a split-operand launch's max |out| no longer describes this buffer
     rp, rs = (None, 0) if residual is None else _rows(_dev(residual, 'residual'), 'residual')
     tb, tc = (0, (pl.out + 127) // 128) if tiles is None else tiles
 

@@ -38,7 +38,7 @@ class MaskedLinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual, layer, relu_in):
         ctx.x_max = None
         if _split_mode(x, layer.in_features):
-            ctx.x_max = getattr(x, '_nf_max', None)
+            ctx.x_max = _lib.tagged_max(x)
             if ctx.x_max is None:
                 ctx.x_max = _lib.maxabs(x)
             y = _lib.masked_linear_split(x, layer._packed_linear_split(), residual=residual, relu_in=relu_in,

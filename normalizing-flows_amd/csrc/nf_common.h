@@ -26,3 +26,18 @@ static inline int nf_launch_status() {
 }
 
 static inline int nf_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// MaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: raise it once per (kernel, device).
+// `done` is the call site's bitmask over device ordinals 0..63 (atomic: entry points are thread-safe for distinct
+// streams); ordinals past 63 set the attribute on every launch.  Not an allocation.
+static inline int nf_raise_lds_cap(const void* kernel, unsigned long long* done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? 1ull << dev : 0ull;
+    if (bit && (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit)) return NF_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    if (bit) __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
+    return NF_OK;
+}

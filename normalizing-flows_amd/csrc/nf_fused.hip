@@ -1197,7 +1197,13 @@ __global__ __launch_bounds__(256) void maxabs_rows_kernel(const float* __restric
         const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));   // fmaxf drops NaN
         m = fmaxf(m, a < INFINITY ? a : 0.f);
     };
-    if (ldh == K) {                                  // contiguous: one flat array, 4 independent loads in flight
+    if (K % 4 != 0 || ldh % 4 != 0 || ((uintptr_t)h & 15) != 0) {     // ragged / unaligned rows: scalar loads
+        for (int64_t r = blockIdx.x; r < M; r += gridDim.x)
+            for (int c = threadIdx.x; c < K; c += 256) {
+                const float a = fabsf(h[r * ldh + c]);
+                m = fmaxf(m, a < INFINITY ? a : 0.f);
+            }
+    } else if (ldh == K) {                                  // contiguous: one flat array, 4 independent loads in flight
         const int64_t total = M * cpr, stride = (int64_t)gridDim.x * 256;
         const float4* p = reinterpret_cast<const float4*>(h);
         int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1262,13 +1268,9 @@ inline size_t lds_bytes_split(int fpt, int P, int nt) {
 
 template <class SP, int KT, bool INV, bool PRE>
 int launch_one_split(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)made_rqs_split_kernel<SP, KT, INV, PRE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long cap_done = 0;
+    const int rc = nf_raise_lds_cap((const void*)made_rqs_split_kernel<SP, KT, INV, PRE>, &cap_done);
+    if (rc != NF_OK) return rc;
     hipLaunchKernelGGL((made_rqs_split_kernel<SP, KT, INV, PRE>), dim3(grid), dim3(XT), lds, s, g);
     return nf_launch_status();
 }
@@ -1287,7 +1289,7 @@ int launch_k_split(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
 inline int maxabs_rows(const float* h, int64_t ld, int64_t B, int cols, unsigned* slot, hipStream_t s) {
     hipError_t me = hipMemsetAsync(slot, 0, sizeof(unsigned), s);
     if (me != hipSuccess) return (int)me;
-    const int64_t q4 = B * (cols / 4);
+    const int64_t q4 = B * ((cols + 3) / 4);
     const int mgrid = (int)((q4 + 255) / 256 < 2048 ? (q4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(maxabs_rows_kernel, dim3(mgrid), dim3(256), 0, s, h, ld, B, cols, slot);
     return nf_launch_status();
@@ -1324,13 +1326,9 @@ inline size_t lds_bytes(int fpt, int P) {
 
 template <bool BF16, int KT, bool INV>
 int launch_one(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;          // raise the dynamic-LDS cap once per instantiation (not an allocation)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)made_rqs_kernel<BF16, KT, INV>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long cap_done = 0;     // dynamic-LDS cap: once per instantiation and device
+    const int rc = nf_raise_lds_cap((const void*)made_rqs_kernel<BF16, KT, INV>, &cap_done);
+    if (rc != NF_OK) return rc;
     hipLaunchKernelGGL((made_rqs_kernel<BF16, KT, INV>), dim3(grid), dim3(FT), lds, s, g);
     return nf_launch_status();
 }
@@ -1582,26 +1580,20 @@ extern "C" int nf_linear_split_repack(const float* W, const float* mask, const f
 }
 
 extern "C" int nf_maxabs(const float* x, int64_t x_row_stride, int64_t B, int cols, uint32_t* slot, void* stream) {
-    if (B < 0 || cols <= 0 || cols % 4 != 0) return NF_ERR_SHAPE;
+    if (B < 0 || cols <= 0) return NF_ERR_SHAPE;
     if (!slot) return NF_ERR_NULL;
     if (B == 0) return (int)hipMemsetAsync(slot, 0, sizeof(uint32_t), (hipStream_t)stream);
     if (!x) return NF_ERR_NULL;
-    if (x_row_stride < cols || x_row_stride % 4 != 0 || ((uintptr_t)x & 15) != 0) return NF_ERR_LAYOUT;
+    if (x_row_stride < cols) return NF_ERR_LAYOUT;
     return maxabs_rows(x, x_row_stride, B, cols, (unsigned*)slot, (hipStream_t)stream);
 }
 
 template <class SP>
 static int launch_linear_split(const FusedArgs& g, int grid, size_t lds, int relu_in, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)masked_linear_split_kernel<SP, false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipError_t e2 = hipFuncSetAttribute((const void*)masked_linear_split_kernel<SP, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e1 != hipSuccess) return (int)e1;
-        if (e2 != hipSuccess) return (int)e2;
-        attr_set = true;
-    }
+    static unsigned long long cap_done[2] = {0, 0};
+    const int rc = relu_in ? nf_raise_lds_cap((const void*)masked_linear_split_kernel<SP, true>, &cap_done[1])
+                           : nf_raise_lds_cap((const void*)masked_linear_split_kernel<SP, false>, &cap_done[0]);
+    if (rc != NF_OK) return rc;
     if (relu_in) hipLaunchKernelGGL((masked_linear_split_kernel<SP, true>), dim3(grid), dim3(XT), lds, s, g);
     else hipLaunchKernelGGL((masked_linear_split_kernel<SP, false>), dim3(grid), dim3(XT), lds, s, g);
     return nf_launch_status();
@@ -1669,16 +1661,10 @@ extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_s
     const int64_t grid = (work + g.group - 1) / g.group * g.group;      // whole groups, then whole rounds of 8 XCDs
     const int64_t blocks = (grid / g.group + 7) / 8 * 8 * g.group;
     if (blocks > 0x7fffffff) return NF_ERR_SHAPE;
-    static bool attr_set = false;          // raise the dynamic-LDS cap once (not an allocation)
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)wgrad_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            160 * 1024);
-        hipError_t e2 = hipFuncSetAttribute((const void*)wgrad_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            160 * 1024);
-        if (e1 != hipSuccess) return (int)e1;
-        if (e2 != hipSuccess) return (int)e2;
-        attr_set = true;
-    }
+    static unsigned long long cap_done[2] = {0, 0};
+    const int rc = tw == 2 ? nf_raise_lds_cap((const void*)wgrad_split_kernel<2>, &cap_done[1])
+                           : nf_raise_lds_cap((const void*)wgrad_split_kernel<1>, &cap_done[0]);
+    if (rc != NF_OK) return rc;
     const size_t lds = (size_t)2 * 2 * (128 * tw + 128) * WSLD * sizeof(_Float16);       // 2 buffers x 2 terms
     if (tw == 2)
         hipLaunchKernelGGL(wgrad_split_kernel<2>, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);

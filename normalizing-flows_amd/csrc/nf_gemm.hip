@@ -462,9 +462,25 @@ struct WgradArgs {
     int splits;
 };
 
+template <bool VEC>
 __device__ __forceinline__ float4 ld4_rows(const float* base, int64_t ld, int64_t row, int64_t M, int col, int ncols) {
     // rows past M and columns past ncols contribute zeros (clamped address, select afterwards)
     const int64_t r = min(row, M - 1);
+    if (!VEC) {
+        // ragged layers (widths not a multiple of 4, rows not 16-byte aligned): four scalar loads, each bounded
+        const float* p = base + r * ld;
+        float4 v;
+        v.x = p[min(col, ncols - 1)];
+        v.y = p[min(col + 1, ncols - 1)];
+        v.z = p[min(col + 2, ncols - 1)];
+        v.w = p[min(col + 3, ncols - 1)];
+        const bool in = row < M;
+        v.x = (in && col < ncols) ? v.x : 0.f;
+        v.y = (in && col + 1 < ncols) ? v.y : 0.f;
+        v.z = (in && col + 2 < ncols) ? v.z : 0.f;
+        v.w = (in && col + 3 < ncols) ? v.w : 0.f;
+        return v;
+    }
     const int c = min(col, ncols - 4);
     float4 v = *reinterpret_cast<const float4*>(base + r * ld + c);
     const bool ok = row < M && col < ncols;
@@ -475,6 +491,7 @@ __device__ __forceinline__ float4 ld4_rows(const float* base, int64_t ld, int64_
     return v;
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(GT, 2) void wgrad_f32_kernel(const WgradArgs g) {
     __shared__ __attribute__((aligned(16))) float Ys[WB * WLD];
     __shared__ __attribute__((aligned(16))) float Xs[WB * WLD];
@@ -504,14 +521,14 @@ __global__ __launch_bounds__(GT, 2) void wgrad_f32_kernel(const WgradArgs g) {
 #define NF_WG_LOAD(B0)                                                              \
     do {                                                                            \
         const int64_t b_ = (B0) + srow;                                             \
-        y0 = ld4_rows(g.gy, g.ldgy, b_, b_end, n0 + scol, g.out);                   \
-        y1 = ld4_rows(g.gy, g.ldgy, b_ + 8, b_end, n0 + scol, g.out);               \
-        y2 = ld4_rows(g.gy, g.ldgy, b_ + 16, b_end, n0 + scol, g.out);              \
-        y3 = ld4_rows(g.gy, g.ldgy, b_ + 24, b_end, n0 + scol, g.out);              \
-        x0 = ld4_rows(g.x, g.ldx, b_, b_end, k0 + scol, g.in);                      \
-        x1 = ld4_rows(g.x, g.ldx, b_ + 8, b_end, k0 + scol, g.in);                  \
-        x2 = ld4_rows(g.x, g.ldx, b_ + 16, b_end, k0 + scol, g.in);                 \
-        x3 = ld4_rows(g.x, g.ldx, b_ + 24, b_end, k0 + scol, g.in);                 \
+        y0 = ld4_rows<VEC>(g.gy, g.ldgy, b_, b_end, n0 + scol, g.out);                   \
+        y1 = ld4_rows<VEC>(g.gy, g.ldgy, b_ + 8, b_end, n0 + scol, g.out);               \
+        y2 = ld4_rows<VEC>(g.gy, g.ldgy, b_ + 16, b_end, n0 + scol, g.out);              \
+        y3 = ld4_rows<VEC>(g.gy, g.ldgy, b_ + 24, b_end, n0 + scol, g.out);              \
+        x0 = ld4_rows<VEC>(g.x, g.ldx, b_, b_end, k0 + scol, g.in);                      \
+        x1 = ld4_rows<VEC>(g.x, g.ldx, b_ + 8, b_end, k0 + scol, g.in);                  \
+        x2 = ld4_rows<VEC>(g.x, g.ldx, b_ + 16, b_end, k0 + scol, g.in);                 \
+        x3 = ld4_rows<VEC>(g.x, g.ldx, b_ + 24, b_end, k0 + scol, g.in);                 \
     } while (0)
     auto relu4 = [&](float4 v) {
         if (g.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -776,7 +793,8 @@ extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const 
 // grad_w[out,in] += mask * (grad_y^T @ act(x)), grad_b[out] += column sums of grad_y (either may be NULL).
 // Both are ACCUMULATED (zero them before the first call); with the batch split across blocks the sums
 // use fp32 atomics, so the last bits depend on arrival order.  `ktab` (nullable) is the forward K-tile table
-// of this layer: output tiles without unmasked weights are skipped.  Requires in % 4 == 0 and out % 4 == 0.
+// of this layer: output tiles without unmasked weights are skipped.  Any widths / alignment (ragged shapes take
+// scalar loads).
 extern "C" int nf_masked_linear_bwd_weight(const float* x, int64_t x_row_stride, const float* grad_y,
                                            int64_t grad_y_row_stride, const float* mask, const int32_t* ktab,
                                            float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
@@ -786,8 +804,9 @@ extern "C" int nf_masked_linear_bwd_weight(const float* x, int64_t x_row_stride,
     if (B == 0) return NF_OK;
     if (!x || !grad_y || (!grad_w && !grad_b)) return NF_ERR_NULL;
     if (x_row_stride < in || grad_y_row_stride < out) return NF_ERR_LAYOUT;
-    if (in % 4 || out % 4 || x_row_stride % 4 || grad_y_row_stride % 4 || (((uintptr_t)x | (uintptr_t)grad_y) & 15))
-        return NF_ERR_LAYOUT;
+    // 16-byte loads when both operands allow them, else the bounded scalar-load flavour (D = 2, K = 4 ...)
+    const bool vec = !(in % 4 || out % 4 || x_row_stride % 4 || grad_y_row_stride % 4 ||
+                       (((uintptr_t)x | (uintptr_t)grad_y) & 15));
     hipStream_t s = (hipStream_t)stream;
     if (grad_w) {
         WgradArgs g;
@@ -800,7 +819,8 @@ extern "C" int nf_masked_linear_bwd_weight(const float* x, int64_t x_row_stride,
         if (splits > max_splits) splits = max_splits;
         if (splits > 65535) splits = 65535;
         g.splits = (int)splits;
-        hipLaunchKernelGGL(wgrad_f32_kernel, dim3(nt, kt, (int)splits), dim3(GT), 0, s, g);
+        if (vec) hipLaunchKernelGGL(wgrad_f32_kernel<true>, dim3(nt, kt, (int)splits), dim3(GT), 0, s, g);
+        else hipLaunchKernelGGL(wgrad_f32_kernel<false>, dim3(nt, kt, (int)splits), dim3(GT), 0, s, g);
     }
     if (grad_b) {
         int64_t rs = (B + 1023) / 1024;

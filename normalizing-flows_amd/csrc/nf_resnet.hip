@@ -142,13 +142,9 @@ extern "C" int nf_resnet_hidden_fwd(const float* x, int64_t x_row_stride, const 
     const size_t lds = sizeof(float) * 2 * RM * (size_t)(wmax + 4);
     const int64_t grid = (B + RM - 1) / RM;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)resnet_hidden_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long cap_done = 0;
+    const int rc = nf_raise_lds_cap((const void*)resnet_hidden_kernel, &cap_done);
+    if (rc != NF_OK) return rc;
     hipLaunchKernelGGL(resnet_hidden_kernel, dim3((unsigned)grid), dim3(RT), lds, (hipStream_t)stream, g);
     return nf_launch_status();
 }

@@ -65,7 +65,9 @@ class StandardNormal(Distribution):
     def __init__(self, shape, device=None):
         super().__init__()
         self._shape = torch.Size([shape] if isinstance(shape, int) else shape)
-        self.register_buffer('_anchor', torch.zeros(1, device=device))
+        # follows .to() / .cuda() like a buffer, but is NOT part of the state_dict: the reference's base distribution is
+        # not an nn.Module, so a reference-keyed state_dict has no such entry (strict=True loads both ways)
+        self.register_buffer('_anchor', torch.zeros(1, device=device), persistent=False)
         self.generator = None
 
     def _log_prob(self, inputs, context=None):

@@ -139,7 +139,8 @@ class _PackedMixin:
 
     def fused(self, x, residual=None, in_scale=None, in_shift=None, relu_in=False, relu_out=False, out=None,
               tiles=None):
-        if _training(self) or (torch.is_grad_enabled() and x.requires_grad):
+        if _training(self) or (torch.is_grad_enabled() and (x.requires_grad or
+                                                            (residual is not None and residual.requires_grad))):
             if in_scale is not None or relu_out or out is not None or tiles is not None:
                 _require_inference(self)
                 raise NotImplementedError('no backward kernel for BatchNorm / feed-forward blocks')

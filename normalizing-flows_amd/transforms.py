@@ -90,16 +90,18 @@ class AutoregressiveTransform(nn.Module):
             return outputs, logabsdet
         # per launch group; what the kernels attach to a group's output (max |y| of the split-operand kernels)
         # is kept per group on the full tensor and re-attached to the next layer's slices
-        have = getattr(inputs, '_nf_chunk_max', None) or {}
+        # (valid only for the storage and version they were taken at: an in-place write in between drops them)
+        have = getattr(inputs, '_nf_chunk_max', None)
+        have = have[0] if have is not None and have[1:] == (inputs._version, inputs.data_ptr()) else {}
         keep = {}
         for s in range(0, B, CHUNK_ROWS):
             e = min(B, s + CHUNK_ROWS)
             ctx = None if context is None else context[s:e]
             xin, yout = inputs[s:e], outputs[s:e]
-            xin._nf_max = have.get((s, e))
+            _lib.tag_max(xin, have.get((s, e)))
             self._transform_rows(xin, xin, ctx, yout, logabsdet[s:e], inverse=False)
-            keep[(s, e)] = getattr(yout, '_nf_max', None)
-        outputs._nf_chunk_max = keep
+            keep[(s, e)] = _lib.tagged_max(yout)
+        outputs._nf_chunk_max = (keep, outputs._version, outputs.data_ptr())
         return outputs, logabsdet
 
     def _forward_autograd(self, inputs, context):

@@ -583,7 +583,7 @@ def test_split_operand_hidden_gemm_ragged_vs_fp64(nf, mode):
         pls = nf._lib.PackedLinearSplit(W.cuda(), mask.cuda(), bias.cuda(), dtype)
         got = nf._lib.masked_linear_split(x.cuda(), pls, residual=res.cuda(), relu_in=True)
         assert_close(got, want, want32)
-        slot = got._nf_max.view(torch.float32).item()
+        slot = nf._lib.tagged_max(got).view(torch.float32).item()
         assert abs(slot - got.abs().max().item()) <= 1e-6 * max(1.0, slot)
         # second layer fed by the first (uses the slot), ReLU on the way out
         W2 = torch.randn(16, N, generator=g) * 0.1
@@ -798,7 +798,10 @@ def _oracle_loss(sds, x, K, Tb):
     return -O.flow_log_prob(fwd, x).mean()
 
 
-@pytest.mark.parametrize('D,H,K,B', [(16, 32, 8, 96), (40, 136, 4, 130)])
+@pytest.mark.parametrize('D,H,K,B', [(16, 32, 8, 96), (40, 136, 4, 130),
+                                     # ragged layers (widths not multiples of 4, rows not 16-byte aligned: the
+                                     # scalar-load weight-gradient flavour): two-moons D = 2, D = 6 with K = 4 (out 66)
+                                     (2, 6, 4, 37), (6, 14, 4, 45), (9, 13, 5, 33), (10, 64, 8, 70)])
 def test_training_gradients_match_autograd_of_the_oracle(nf, D, H, K, B):
     """d(-mean log_prob)/d(every weight, bias and input) from the backward kernels (masked-linear dgrad /
     wgrad with the mask re-applied, spline recompute-backward) against torch autograd through the oracle's
@@ -842,6 +845,8 @@ def test_training_gradients_in_split_operand_modes(nf, mode):
     try:
         test_training_gradients_match_autograd_of_the_oracle(nf, 40, 136, 4, 130)
         test_training_gradients_match_autograd_of_the_oracle(nf, 16, 32, 8, 96)
+        test_training_gradients_match_autograd_of_the_oracle(nf, 6, 14, 4, 45)      # ragged: falls to fp32 MFMA
+        test_training_gradients_match_autograd_of_the_oracle(nf, 10, 64, 8, 70)     # hidden layers split, ragged ends
     finally:
         nf.set_matmul_dtype('f32')
 
@@ -1215,7 +1220,7 @@ def test_split_gemm_gate_epilogue(nf, out):
     gated = _lib.masked_linear_split(x, pls, gate=gate)
     want = plain * (gate > 0)
     assert torch.equal(gated, want)
-    slot = gated._nf_max.view(torch.float32).item()
+    slot = nf._lib.tagged_max(gated).view(torch.float32).item()
     assert slot == want.abs().max().item()
     with pytest.raises(ValueError):
         _lib.masked_linear_split(x, pls, gate=gate, relu_out=True)
