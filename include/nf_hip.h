@@ -202,6 +202,22 @@ int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h
                          int tails, double tail_bound, double min_bin_width, double min_bin_height,
                          double min_derivative, int inverse, int dtype, void* stream);
 
+/* nf_made_rqs_fwd WITHOUT a workspace argument and without any allocation.  No counterpart in the reference: it is
+ * for callers that cannot allocate - code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  The per-tile logdet partials (for the split-operand dtypes also the hidden state's scale slot and, when
+ * they fit, its term planes) live in an 8 MiB device array inside the library, one copy per GPU, held until the
+ * process ends.  Limit: nf_made_rqs_tiles(features, K, tails) * B * 4 bytes (+ 512 for NF_DTYPE_F16X2 / BF16X3) must
+ * fit 8 MiB (cfg-3 shape, 72 tiles: B <= 29127), else NF_ERR_SCRATCH and nothing is launched.  Calls no hipMalloc /
+ * hipFree / allocating routine; the first call on a device resolves that device's copy of the array (make it outside
+ * graph capture; B = 0 does that and launches nothing).  Every call on a GPU shares that GPU's array: calls that
+ * overlap on one GPU (different streams or threads) race - serialise them.  Nothing in the array needs to start at
+ * zero (every value read is written first by the same call).  Results are those of nf_made_rqs_fwd, bit for bit. */
+int nf_made_rqs_fwd_noalloc(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                            const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                            int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx, int64_t B, int in,
+                            int features, int K, int tails, double tail_bound, double min_bin_width,
+                            double min_bin_height, double min_derivative, int inverse, int dtype, void* stream);
+
 /* ---- hidden-layer GEMMs on split operands (NF_DTYPE_F16X2 / NF_DTYPE_BF16X3; replaces made.py:150-152 like
  *      nf_masked_linear_fwd, same fp32 contract, fp16 / bf16 matrix pipe) --------------------------------- */
 

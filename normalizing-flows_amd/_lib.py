@@ -124,6 +124,11 @@ _SIGNATURES = {
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                    _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_int,
                                    _c.c_void_p]),
+    'nf_made_rqs_fwd_noalloc': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                           _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                           _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_int,
+                                           _c.c_void_p]),
     'nf_made_pack_t': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
                                   _c.c_void_p, _c.c_void_p]),
     'nf_masked_linear_bwd_input': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,

@@ -11,7 +11,9 @@ extern "C" const char* nf_strerror(int code) {
         case NF_ERR_LAYOUT: return "stride or alignment not accepted";
         case NF_ERR_BINS: return "minimal bin width/height too large for the number of bins";
         case NF_ERR_DTYPE: return "unknown dtype or layout";
-        case NF_ERR_SCRATCH: return "workspace too small";
+        case NF_ERR_SCRATCH:
+            return "workspace too small (nf_made_rqs_fwd_noalloc: the batch exceeds its static scratch, tiles * B * 4 bytes "
+                   "must fit 8 MiB)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }

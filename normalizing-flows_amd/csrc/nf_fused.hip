@@ -1672,3 +1672,51 @@ extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_s
         hipLaunchKernelGGL(wgrad_split_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
     return nf_launch_status();
 }
+
+// ---- the one entry point that allocates nothing and takes no workspace ---------------------------------
+// nf_made_rqs_fwd for callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that
+// forbid hipMalloc): the per-tile logdet partials (and, for the split-operand dtypes, the hidden state's scale
+// slot and - when they fit - its term planes) live in a file-scope device array instead of a caller workspace.
+// Every GPU the library runs on holds its own copy of the array at its own address until the process ends; the
+// address is resolved once per device with that device current (hipGetSymbolAddress) and only that pointer is
+// ever handed to kernels - the array's name in host code is a host-side stand-in, not a device address.
+#define NF_NOALLOC_SCRATCH_BYTES (8u << 20)
+static __device__ __align__(256) unsigned char nf_noalloc_scratch[NF_NOALLOC_SCRATCH_BYTES];
+#define NF_NOALLOC_MAX_DEVICES 64
+static void* nf_noalloc_ptr[NF_NOALLOC_MAX_DEVICES];       // per device ordinal, NULL until resolved
+
+static int nf_noalloc_scratch_of_current_device(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= NF_NOALLOC_MAX_DEVICES) return NF_ERR_SHAPE;
+    void* p = __atomic_load_n(&nf_noalloc_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(nf_noalloc_scratch));       // this device's copy of the array
+        if (e != hipSuccess) return (int)e;
+        if (!p) return NF_ERR_NULL;
+        __atomic_store_n(&nf_noalloc_ptr[dev], p, __ATOMIC_RELEASE);       // (racing first calls resolve the same address)
+    }
+    *out = p;
+    return NF_OK;
+}
+
+extern "C" int nf_made_rqs_fwd_noalloc(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                                       const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                                       int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx,
+                                       int64_t B, int in, int features, int K, int tails, double tail_bound,
+                                       double min_bin_width, double min_bin_height, double min_derivative, int inverse,
+                                       int dtype, void* stream) {
+    void* scratch = nullptr;
+    const int rc = nf_noalloc_scratch_of_current_device(&scratch);          // also on B == 0: a warm-up call resolves it
+    if (rc != NF_OK) return rc;
+    if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
+    // the partials (+ the split dtypes' 256-byte scale slot) must fit the static array: NF_ERR_SCRATCH otherwise
+    size_t need = nf_made_rqs_workspace_bytes(B, features, K, tails);
+    if (split_terms(dtype)) need = (need + 255) / 256 * 256 + 256;
+    if (need > NF_NOALLOC_SCRATCH_BYTES) return NF_ERR_SCRATCH;
+    return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr,
+                          features, logabsdet, accumulate, bin_idx, (float*)scratch, NF_NOALLOC_SCRATCH_BYTES, B, in,
+                          features, K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
+                          nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, nullptr, stream);
+}
