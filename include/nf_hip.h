@@ -390,6 +390,31 @@ int nf_maf_reverse_step(const double* x, int64_t x_row_stride, const double* mad
                         double* z, int64_t z_row_stride, double* logJ, int64_t B, int D, int dim,
                         int reverse_input, void* stream);
 
+/* Backward of the three above (the reference trains this class by autograd through flows.py:239-263 and made.py:20-21:
+ * test2.py:127-135, model.py:233-244; cfg-1's "short training").
+ * nf_linear_f64_bwd: g = grad_y zeroed where relu_out clipped the forward output y (y: the forward result, needed only
+ * when relu_out); grad_x = g @ folded_w, grad_w = mask * (g^T @ x) (mask NULL = dense; WRITTEN, fixed-order sums, no
+ * atomics), grad_b = column sums of g.  grad_x / grad_w / grad_b may each be NULL. */
+int nf_linear_f64_bwd(const double* x, int64_t x_row_stride, const double* y, int64_t y_row_stride,
+                      const double* folded_w, const double* mask, const double* grad_y, int64_t grad_y_row_stride,
+                      double* grad_x, int64_t grad_x_row_stride, double* grad_w, double* grad_b, int64_t B, int in,
+                      int out, int relu_out, void* stream);
+/* Backward of nf_maf_fwd: from grad_x [B,D] and grad_logJ [B] (either may be NULL = 0) to grad_z (the direct part)
+ * and grad_made_out [B,2D] = [grad_mu | grad_logp]. */
+int nf_maf_bwd(const double* z, int64_t z_row_stride, const double* made_out, int64_t out_row_stride,
+               const double* grad_x, int64_t grad_x_row_stride, const double* grad_logJ, double* grad_z,
+               int64_t grad_z_row_stride, double* grad_made_out, int64_t grad_out_row_stride, int64_t B, int D,
+               int reverse_input, void* stream);
+/* Backward of one nf_maf_reverse_step pass taken out of place (z_new = z_old with column `dim` rebuilt): from
+ * grad_z_new [B,D] and, for the pass that produced logJ, grad_logJ [B] (NULL otherwise) to grad_x [B,D] (zero except
+ * the column the pass read), grad_made_out [B,2D] and grad_z_old [B,D] (grad_z_new with column `dim` zeroed; the part
+ * through made_out comes from the conditioner's backward).  The clamp at 10 passes gradient where -logp/2 <= 10. */
+int nf_maf_reverse_step_bwd(const double* x, int64_t x_row_stride, const double* made_out, int64_t out_row_stride,
+                            const double* grad_z_new, int64_t grad_z_new_row_stride, const double* grad_logJ,
+                            double* grad_x, int64_t grad_x_row_stride, double* grad_made_out,
+                            int64_t grad_out_row_stride, double* grad_z_old, int64_t grad_z_old_row_stride, int64_t B,
+                            int D, int dim, int reverse_input, void* stream);
+
 /* ---- diagnostics (no reference counterpart): what this device sustains, printed by bench.py beside the
  *      nominal roofline peaks ------------------------------------------------------------------------- */
 

@@ -11,7 +11,10 @@ from .transforms import CompositeTransform, AutoregressiveTransform, MaskedAffin
     PiecewiseRationalQuadraticCouplingTransform
 from . import parallel, metrics
 from .checkpoint import save_checkpoint, load_checkpoint
-from .flows import MaskedAutoregressiveFlow, SimpleMADE, SimpleMaskedLinear
+from .flows import MaskedAutoregressiveFlow, SimpleMADE, SimpleMaskedLinear, apply_flow_to_samples, \
+    apply_reverse_to_samples
+from . import data
+from .data import two_moons
 from .distributions import Distribution, StandardNormal, BaseNeuralSplineFlow, Flow
 
 __all__ = [n for n in dir() if not n.startswith('_')]

@@ -147,6 +147,15 @@ _SIGNATURES = {
                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_maf_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p,
                               _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_linear_f64_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
+                                     _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
+                                     _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_maf_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                              _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
+                              _c.c_void_p]),
+    'nf_maf_reverse_step_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                           _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                                           _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_maf_reverse_step': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
                                        _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }
@@ -1006,6 +1015,65 @@ def maf_reverse_step(x, made_out, z, dim, reverse_input, logJ=None):
     with torch.cuda.device(x.device):
         _check(lib.nf_maf_reverse_step(xp, xs, op, os_, zp, zs, _ptr(logJ), B, D, int(dim), int(bool(reverse_input)),
                                        _stream()), 'nf_maf_reverse_step')
+
+
+def linear_f64_bwd(x, y, folded, mask, grad_y, relu_out, want_input=True, want_weight=True, want_bias=True):
+    """(grad_x, grad_w, grad_b) of linear_f64 (any of them None when not wanted); grad_w has the mask re-applied."""
+    lib = load()
+    _dev(x, 'x', torch.float64)
+    _dev(grad_y, 'grad_y', torch.float64)
+    xp, xs = _rows(x, 'x')
+    gp, gs = _rows(grad_y, 'grad_y')
+    yp, ys = _rows(_dev(y, 'y', torch.float64), 'y') if relu_out else (None, 0)
+    B, inp = x.shape
+    out = folded.shape[0]
+    gx = torch.empty((B, inp), dtype=torch.float64, device=x.device) if want_input else None
+    gxp, gxs = (None, 0) if gx is None else _rows(gx, 'grad_x')
+    gw = torch.empty((out, inp), dtype=torch.float64, device=x.device) if want_weight else None
+    gb = torch.empty(out, dtype=torch.float64, device=x.device) if want_bias else None
+    m = None if mask is None else _dev(mask, 'mask', torch.float64)
+    with torch.cuda.device(x.device):
+        _check(lib.nf_linear_f64_bwd(xp, xs, yp, ys, folded.data_ptr(), _ptr(m), gp, gs, gxp, gxs, _ptr(gw), _ptr(gb),
+                                     B, inp, out, int(relu_out), _stream()), 'nf_linear_f64_bwd')
+    return gx, gw, gb
+
+
+def maf_bwd(z, made_out, grad_x, grad_logJ, reverse_input):
+    """(grad_z direct part, grad_made_out) of maf_fwd."""
+    lib = load()
+    B, D = z.shape
+    zp, zs = _rows(_dev(z, 'z', torch.float64), 'z')
+    op, os_ = _rows(_dev(made_out, 'made_out', torch.float64), 'made_out')
+    gxp, gxs = (None, 0) if grad_x is None else _rows(_dev(grad_x, 'grad_x', torch.float64), 'grad_x')
+    gl = None if grad_logJ is None else _dev(grad_logJ.contiguous(), 'grad_logJ', torch.float64)
+    gz = torch.empty_like(z)
+    gzp, gzs = _rows(gz, 'grad_z')
+    go = torch.empty((B, 2 * D), dtype=torch.float64, device=z.device)
+    gop, gos = _rows(go, 'grad_made_out')
+    with torch.cuda.device(z.device):
+        _check(lib.nf_maf_bwd(zp, zs, op, os_, gxp, gxs, _ptr(gl), gzp, gzs, gop, gos, B, D, int(bool(reverse_input)),
+                              _stream()), 'nf_maf_bwd')
+    return gz, go
+
+
+def maf_reverse_step_bwd(x, made_out, grad_z_new, grad_logJ, dim, reverse_input):
+    """(grad_x, grad_made_out, grad_z_old) of one out-of-place maf_reverse_step pass."""
+    lib = load()
+    B, D = x.shape
+    xp, xs = _rows(_dev(x, 'x', torch.float64), 'x')
+    op, os_ = _rows(_dev(made_out, 'made_out', torch.float64), 'made_out')
+    gnp, gns = (None, 0) if grad_z_new is None else _rows(_dev(grad_z_new, 'grad_z_new', torch.float64), 'grad_z_new')
+    gl = None if grad_logJ is None else _dev(grad_logJ.contiguous(), 'grad_logJ', torch.float64)
+    gx = torch.empty_like(x)
+    go = torch.empty((B, 2 * D), dtype=torch.float64, device=x.device)
+    gzo = torch.empty_like(x)
+    gxp, gxs = _rows(gx, 'grad_x')
+    gop, gos = _rows(go, 'grad_made_out')
+    gzp, gzs = _rows(gzo, 'grad_z_old')
+    with torch.cuda.device(x.device):
+        _check(lib.nf_maf_reverse_step_bwd(xp, xs, op, os_, gnp, gns, _ptr(gl), gxp, gxs, gop, gos, gzp, gzs, B, D,
+                                           int(dim), int(bool(reverse_input)), _stream()), 'nf_maf_reverse_step_bwd')
+    return gx, go, gzo
 
 
 # ------------------------------------------------------------------------------------------------ diagnostics

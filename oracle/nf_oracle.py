@@ -23,6 +23,7 @@ Reference lines followed (all under /root/reference):
   coupling (rq / affine) .......................... models/transforms.py:80-135, 156-168, 212-247, 328-347
   residual_net_forward ............................ models/nn/resnet.py:38-57, 90-100
   maf_forward / maf_reverse ....................... models/flows.py:239-263
+  legacy_flow_to_samples / legacy_reverse_to_samples models/model.py:87-108
   composite ....................................... models/transforms.py:21-36
   log_prob / sample ............................... models/model.py:78-108, models/distributions.py:105-107, 154-196
 """
@@ -413,6 +414,23 @@ def maf_reverse(weights, biases, masks, x, reverse_input=True):
         mod = torch.clamp(-0.5 * logp, max=10)
         z[:, dim] = mu[:, dim] + x[:, dim] * torch.exp(mod[:, dim])
     return z, torch.sum(mod, dim=1)
+
+
+def legacy_flow_to_samples(layers, x, logq):
+    """model.py:87-92 over legacy layers: `layers` = [(weights, biases, masks, reverse_input)]."""
+    for w, b, m, ri in layers:
+        x, logJ = maf_forward(w, b, m, x, ri)
+        logq = logq - logJ.squeeze()
+    return x, logq
+
+
+def legacy_reverse_to_samples(layers, x, logq):
+    """model.py:103-108 with a standard-normal prior (distributions.py:105-107): the log-density the stack assigns
+    to data x; cfg-1 trains on `-mean` of it."""
+    for w, b, m, ri in reversed(list(layers)):
+        x, logJ = maf_reverse(w, b, m, x, ri)
+        logq = logq + logJ.squeeze()
+    return x, std_normal_log_prob(x) + logq
 
 
 # --------------------------------------------------------------------------- stacks

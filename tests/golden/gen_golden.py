@@ -374,9 +374,92 @@ def gen_maf():
         torch.set_default_dtype(torch.float32)
 
 
+# ======================================================================= cfg-1: short training of the legacy MAF
+def gen_maf_training():
+    """BASELINE.json configs[0]: 5 MaskedAutoregressiveFlow(2, [64]) layers, float64, trained on two-moons data by
+    the reference's own loop - Adam(lr 5e-3) + CosineAnnealingLR(250) for 250 steps of 2**14 fresh samples
+    (test2.py:24-27, 127-135; model.py:233-244), loss = -mean of the density model.py:103-108 assigns to the batch
+    (`apply_reverse_to_samples` with the SimpleNormal prior: forward KL up to the data entropy).  The data definition
+    is this build's (normalizing-flows_amd/data.py, a CPU generator: the same points on every machine)."""
+    from models import distributions as ref_dist
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('nf_data', os.path.join(ROOT, 'normalizing-flows_amd', 'data.py'))
+    nf_data = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(nf_data)
+    torch.set_default_dtype(torch.float64)
+    try:
+        D, L, steps, B, lr = 2, 5, 250, 2 ** 14, 5e-3
+        torch.manual_seed(71)
+        layers = torch.nn.ModuleList([flows.MaskedAutoregressiveFlow(D, [64], reverse_input=(j % 2 == 0))
+                                      for j in range(L)])
+        prior = ref_dist.SimpleNormal(torch.zeros(D), torch.ones(D))
+        arrays = {'dim': D, 'n_layers': L, 'steps': steps, 'batch': B, 'lr': lr, 'data_seed': 2024}
+        for j, f in enumerate(layers):
+            arrays['l%d/reverse_input' % j] = int(f.reverse_input)
+            lin = [m for m in f.made.model if isinstance(m, made.SimpleMaskedLinear)]
+            for i, m in enumerate(lin):
+                arrays['l%d/w%d' % (j, i)] = m.weight.detach().clone()
+                arrays['l%d/b%d' % (j, i)] = m.bias.detach().clone()
+                arrays['l%d/m%d' % (j, i)] = m.mask
+
+        def log_density(x):                            # model.py:103-108, logq = 0
+            logq = 0
+            for layer in reversed(layers):
+                x, logJ = layer.reverse(x)
+                logq = logq + logJ.squeeze()
+            return prior.log_prob(x) + logq
+
+        x_eval = nf_data.two_moons(512, torch.Generator().manual_seed(7))
+        with torch.no_grad():
+            arrays['eval_x'] = x_eval
+            arrays['eval_logp_before'] = log_density(x_eval)
+        # one gradient before training, for the backward kernels alone (first batch of the run)
+        gen = torch.Generator().manual_seed(2024)
+        opt = torch.optim.Adam(layers.parameters(), lr=lr)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, steps, 0)
+        losses = []
+        for step in range(steps):                      # model.py:233-244 train_step
+            x = nf_data.two_moons(B, gen)
+            opt.zero_grad()
+            loss = -log_density(x).mean()
+            loss.backward()
+            if step == 0:
+                for j, f in enumerate(layers):
+                    lin = [m for m in f.made.model if isinstance(m, made.SimpleMaskedLinear)]
+                    for i, m in enumerate(lin):
+                        arrays['l%d/gw%d_step0' % (j, i)] = m.weight.grad.clone()
+                        arrays['l%d/gb%d_step0' % (j, i)] = m.bias.grad.clone()
+            opt.step()
+            sched.step()
+            losses.append(loss.item())
+        arrays['loss'] = np.array(losses)
+        for j, f in enumerate(layers):
+            lin = [m for m in f.made.model if isinstance(m, made.SimpleMaskedLinear)]
+            for i, m in enumerate(lin):
+                arrays['l%d/w%d_final' % (j, i)] = m.weight.detach()
+                arrays['l%d/b%d_final' % (j, i)] = m.bias.detach()
+        with torch.no_grad():
+            arrays['eval_logp_after'] = log_density(x_eval)
+            # the other direction on the trained model (model.py:87-92 from prior samples)
+            z = torch.randn(256, D, generator=torch.Generator().manual_seed(9))
+            h, logq = z, prior.log_prob(z)
+            for layer in layers:
+                h, logJ = layer.forward(h)
+                logq = logq - logJ.squeeze()
+            arrays.update(flow_z=z, flow_x=h, flow_logq=logq)
+        print('maf training: loss %.6f -> %.6f' % (losses[0], losses[-1]))
+        save('maf_train_moons', **arrays)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'maf_training':
+        gen_maf_training()
+        sys.exit(0)
     gen_spline()
     gen_made()
     gen_rq_ar()
     gen_affine_coupling()
     gen_maf()
+    gen_maf_training()

@@ -792,6 +792,119 @@ def test_maf_legacy_fp64_golden(nf, D):
             assert rel_err(r.cpu(), fx['l%d/rev_z' % j]) < 1e-11 and rel_err(lj.cpu(), fx['l%d/rev_logJ' % j]) < 1e-11
 
 
+def _legacy_layers(nf, fx, final=False):
+    sfx = '_final' if final else ''
+    layers = []
+    for j in range(int(fx['n_layers'])):
+        n = sum(1 for k in fx if k.startswith('l%d/m' % j))
+        f = nf.MaskedAutoregressiveFlow(int(fx['dim']), [64], reverse_input=bool(fx['l%d/reverse_input' % j]))
+        sd = {}
+        for i in range(n):
+            sd['made.model.%d.weight' % (2 * i)] = T(fx['l%d/w%d%s' % (j, i, sfx)])
+            sd['made.model.%d.bias' % (2 * i)] = T(fx['l%d/b%d%s' % (j, i, sfx)])
+        f.load_reference(sd, [T(fx['l%d/m%d' % (j, i)]) for i in range(n)])
+        layers.append(f)
+    return torch.nn.ModuleList(layers).cuda()
+
+
+def test_cfg1_two_moons_short_training_follows_the_reference(nf):
+    """BASELINE.json configs[0] end to end on the GPU: the 5-layer legacy MAF (float64) trained for the reference's
+    250 Adam + cosine steps on the same two-moons stream (fixture written by gen_golden.gen_maf_training from the
+    reference's own layers and loop).  Loss per step, the first-step gradients, the final weights and the densities
+    of held-out points before / after follow the reference; forward / linear / reverse-pass backward kernels are
+    what produces every gradient here."""
+    fx = load_golden('maf_train_moons')
+    prior = nf.StandardNormal([2]).cuda()
+    # densities on the reference's initial and final weights (inference kernels)
+    x_eval = dev(fx['eval_x'])
+    for final, key in ((False, 'eval_logp_before'), (True, 'eval_logp_after')):
+        with torch.no_grad():
+            _, lp = nf.apply_reverse_to_samples(_legacy_layers(nf, fx, final), x_eval, 0, prior)
+        assert rel_err(lp.cpu(), fx[key]) < 1e-11
+    layers = _legacy_layers(nf, fx)
+    opt = torch.optim.Adam(layers.parameters(), lr=float(fx['lr']))
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, int(fx['steps']), 0)
+    gen = torch.Generator().manual_seed(int(fx['data_seed']))
+    worst = 0.0
+    for step in range(int(fx['steps'])):
+        x = nf.two_moons(int(fx['batch']), gen).cuda()
+        opt.zero_grad()
+        loss = -nf.apply_reverse_to_samples(layers, x, 0, prior)[1].mean()
+        loss.backward()
+        if step == 0:
+            for j, f in enumerate(layers):
+                for i, lin in enumerate(f.made._linears()):
+                    mask = T(fx['l%d/m%d' % (j, i)])
+                    assert rel_err(lin.weight.grad.cpu(), fx['l%d/gw%d_step0' % (j, i)], floor=1e-3) < 1e-10
+                    assert rel_err(lin.bias.grad.cpu(), fx['l%d/gb%d_step0' % (j, i)], floor=1e-3) < 1e-10
+                    assert (lin.weight.grad.cpu()[mask == 0] == 0).all()
+        opt.step()
+        sched.step()
+        want = float(fx['loss'][step])
+        worst = max(worst, abs(loss.item() - want) / max(1.0, abs(want)))
+    # fp64 sums in another order than ATen's, amplified by 250 Adam steps: measured 3.5e-10; the bar leaves two decades
+    print('cfg-1 training: worst relative loss deviation over the run %.3e' % worst)
+    assert worst < 1e-7, worst
+    for j, f in enumerate(layers):
+        for i, lin in enumerate(f.made._linears()):
+            assert rel_err(lin.weight.detach().cpu(), fx['l%d/w%d_final' % (j, i)], floor=1e-2) < 1e-5
+            assert rel_err(lin.bias.detach().cpu(), fx['l%d/b%d_final' % (j, i)], floor=1e-2) < 1e-5
+    with torch.no_grad():
+        _, lp = nf.apply_reverse_to_samples(layers, x_eval, 0, prior)
+        assert rel_err(lp.cpu(), fx['eval_logp_after']) < 1e-5
+        # prior -> data direction on the reference's trained weights (model.py:78-92)
+        z = dev(fx['flow_z'])
+        xs, logq = nf.apply_flow_to_samples(_legacy_layers(nf, fx, True), z, prior.log_prob(z))
+        assert rel_err(xs.cpu(), fx['flow_x']) < 1e-11 and rel_err(logq.cpu(), fx['flow_logq']) < 1e-11
+
+
+@pytest.mark.parametrize('D,hidden,B', [(2, [64], 300), (5, [16, 24], 77)])
+def test_legacy_maf_backward_both_directions(nf, D, hidden, B):
+    """Gradients of the legacy MAF layer wrt weights, biases and the input, in the forward direction (model.py:87-92,
+    the reverse-KL path) and the D-pass reverse direction (model.py:103-108), against autograd through the oracle."""
+    g = torch.Generator().manual_seed(D)
+    layers = torch.nn.ModuleList([nf.MaskedAutoregressiveFlow(D, hidden, reverse_input=(j % 2 == 0))
+                                  for j in range(3)])
+    for f in layers:
+        for lin in f.made._linears():
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=g, dtype=torch.float64) * 0.3)
+                lin.bias.copy_(torch.randn(lin.bias.shape, generator=g, dtype=torch.float64) * 0.1)
+    ref_layers = [([l.weight.detach().clone().requires_grad_(True) for l in f.made._linears()],
+                   [l.bias.detach().clone().requires_grad_(True) for l in f.made._linears()],
+                   [torch.as_tensor(m).double() for m in f.made.mask_matrix], bool(f.reverse_input)) for f in layers]
+    layers = layers.cuda()
+    prior = nf.StandardNormal([D]).cuda()
+    x = torch.randn(B, D, generator=g, dtype=torch.float64)
+    for direction in ('forward', 'reverse'):
+        for f in layers:
+            f.zero_grad()
+        for w, b, _, _ in ref_layers:
+            for p in w + b:
+                p.grad = None
+        xg = x.clone().cuda().requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        if direction == 'forward':
+            out, logq = nf.apply_flow_to_samples(layers, xg, prior.log_prob(xg))
+            loss = (logq + 0.1 * out.pow(2).sum(1)).mean()
+            ro, rq = O.legacy_flow_to_samples(ref_layers, xr, O.std_normal_log_prob(xr))
+            want = (rq + 0.1 * ro.pow(2).sum(1)).mean()
+        else:
+            out, lp = nf.apply_reverse_to_samples(layers, xg, 0, prior)
+            loss = (-lp + 0.1 * out.pow(2).sum(1)).mean()
+            ro, rp = O.legacy_reverse_to_samples(ref_layers, xr, 0)
+            want = (-rp + 0.1 * ro.pow(2).sum(1)).mean()
+        loss.backward()
+        want.backward()
+        assert abs(loss.item() - want.item()) < 1e-12 * max(1.0, abs(want.item()))
+        assert rel_err(xg.grad.cpu(), xr.grad, floor=1e-3) < 1e-10, direction
+        for f, (w, b, m, _) in zip(layers, ref_layers):
+            for lin, wr, br, mr in zip(f.made._linears(), w, b, m):
+                assert rel_err(lin.weight.grad.cpu(), wr.grad, floor=1e-3) < 1e-10, direction
+                assert rel_err(lin.bias.grad.cpu(), br.grad, floor=1e-3) < 1e-10, direction
+                assert (lin.weight.grad.cpu()[mr == 0] == 0).all()
+
+
 # ------------------------------------------------------------------------------- backward kernels (config 5)
 def _oracle_loss(sds, x, K, Tb):
     fwd = [lambda v, s=s: O.rq_autoregressive_forward(s, v, K, Tb) for s in sds]

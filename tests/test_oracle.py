@@ -256,3 +256,64 @@ def test_cubic_spline_family(tag, direction):
         assert torch.equal(torch.isnan(y), torch.isnan(ry)) and torch.equal(torch.isnan(ld), torch.isnan(rl))
         assert torch.equal(torch.nan_to_num(y), torch.nan_to_num(ry))     # same op sequence => same bits
         assert torch.equal(torch.nan_to_num(ld), torch.nan_to_num(rl))
+
+
+# ------------------------------------------------------------------------------- cfg-1: legacy MAF training
+def _maf_train_layers(fx, final=False, requires_grad=False):
+    sfx = '_final' if final else ''
+    layers = []
+    for j in range(int(fx['n_layers'])):
+        n = sum(1 for k in fx if k.startswith('l%d/m' % j))
+        w = [T(fx['l%d/w%d%s' % (j, i, sfx)]).clone().requires_grad_(requires_grad) for i in range(n)]
+        b = [T(fx['l%d/b%d%s' % (j, i, sfx)]).clone().requires_grad_(requires_grad) for i in range(n)]
+        m = [T(fx['l%d/m%d' % (j, i)]).double() for i in range(n)]
+        layers.append((w, b, m, bool(fx['l%d/reverse_input' % j])))
+    return layers
+
+
+def test_maf_training_fixture_density_and_first_gradient():
+    """cfg-1 (BASELINE.json configs[0]): the oracle's restatement of model.py:103-108 over the legacy layers gives the
+    reference's densities before and after its 250-step run, the reference's first-step gradients (autograd through
+    the same op sequence), and its prior -> data direction on the trained weights."""
+    import normalizing_flows_amd as nf
+    fx = load_golden('maf_train_moons')
+    x_eval = T(fx['eval_x'])
+    assert torch.equal(nf.two_moons(512, torch.Generator().manual_seed(7)), x_eval)       # data definition is stable
+    for final, key in ((False, 'eval_logp_before'), (True, 'eval_logp_after')):
+        with torch.no_grad():
+            _, lp = O.legacy_reverse_to_samples(_maf_train_layers(fx, final), x_eval, 0)
+        assert rel_err(lp, fx[key]) < 1e-13
+    layers = _maf_train_layers(fx, requires_grad=True)
+    x = nf.two_moons(int(fx['batch']), torch.Generator().manual_seed(int(fx['data_seed'])))
+    loss = -O.legacy_reverse_to_samples(layers, x, 0)[1].mean()
+    assert abs(loss.item() - float(fx['loss'][0])) < 1e-13 * abs(float(fx['loss'][0]))
+    loss.backward()
+    for j, (w, b, m, _) in enumerate(layers):
+        for i in range(len(w)):
+            assert rel_err(w[i].grad, fx['l%d/gw%d_step0' % (j, i)], floor=1e-3) < 1e-11
+            assert rel_err(b[i].grad, fx['l%d/gb%d_step0' % (j, i)], floor=1e-3) < 1e-11
+            assert (w[i].grad[m[i] == 0] == 0).all()
+    with torch.no_grad():
+        z = T(fx['flow_z'])
+        xs, logq = O.legacy_flow_to_samples(_maf_train_layers(fx, True), z, O.std_normal_log_prob(z))
+    assert rel_err(xs, fx['flow_x']) < 1e-13 and rel_err(logq, fx['flow_logq']) < 1e-13
+
+
+def test_maf_training_first_steps_follow_the_reference():
+    """The first 20 Adam + cosine steps of the reference's run, redone with the oracle on the same data stream."""
+    import normalizing_flows_amd as nf
+    fx = load_golden('maf_train_moons')
+    layers = _maf_train_layers(fx, requires_grad=True)
+    params = [p for w, b, _, _ in layers for p in w + b]
+    opt = torch.optim.Adam(params, lr=float(fx['lr']))
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, int(fx['steps']), 0)
+    gen = torch.Generator().manual_seed(int(fx['data_seed']))
+    torch.set_num_threads(4)
+    for step in range(20):
+        x = nf.two_moons(int(fx['batch']), gen)
+        opt.zero_grad()
+        loss = -O.legacy_reverse_to_samples(layers, x, 0)[1].mean()
+        loss.backward()
+        opt.step()
+        sched.step()
+        assert abs(loss.item() - float(fx['loss'][step])) < 1e-9 * max(1.0, abs(float(fx['loss'][step]))), step
