@@ -419,7 +419,9 @@ int nf_maf_reverse_step_bwd(const double* x, int64_t x_row_stride, const double*
  *      nominal roofline peaks ------------------------------------------------------------------------- */
 
 /* blocks x 4 waves each issue iters*4 back-to-back MFMAs on 4 accumulators: dtype NF_DTYPE_F32 =
- * v_mfma_f32_32x32x2_f32 (4096 FLOP per wave instruction), NF_DTYPE_BF16 = 32x32x16 (32768 FLOP). */
+ * v_mfma_f32_32x32x2_f32 (4096 FLOP per wave instruction), NF_DTYPE_BF16 = 32x32x16 (32768 FLOP) - both on constant
+ * operands (the datapath barely switches: an upper bound); NF_DTYPE_F16X2 = v_mfma_f32_32x32x16_f16 on pseudo-random
+ * operands that change from one instruction to the next (what the pipe sustains under the power cap on real data). */
 int nf_diag_mfma_loop(float* scratch, int blocks, int iters, int dtype, void* stream);
 /* 16-byte-per-lane device copy of `bytes` (a multiple of 16): the achievable HBM stream rate. */
 int nf_diag_stream_copy(const void* src, void* dst, size_t bytes, void* stream);

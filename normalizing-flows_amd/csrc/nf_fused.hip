@@ -696,6 +696,14 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
     const int f0 = tn * fpt;
     const int fv = min(fpt, g.feat_limit - f0);
 
+#ifdef NF_STAMP
+    long long sp[12];
+    int spn = 0;
+#define XSTAMP() { __builtin_amdgcn_sched_barrier(0); sp[spn++] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define XSTAMP()
+#endif
+    XSTAMP()                                                     // 0: start
     {
         // all of the tile's inputs in flight at once (as a rolled loop every load waited in front of its LDS store:
         // five to six HBM latencies in a row at the head of each workgroup)
@@ -719,8 +727,16 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
         pow2_pair(*g.wmax, ws, wi);
         pow2_pair(*g.hmax, hs, hi);
     }
+    XSTAMP()                                                     // 1: inputs staged
     f32x16 acc[4][2];
+#ifdef NF_KPRIO
+    __builtin_amdgcn_s_setprio(NF_KPRIO);
+#endif
     split_k_loop<SP, PRE, false>(g, lds, m0, tn, tid, ws * hs, hs, acc);
+#ifdef NF_KPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    XSTAMP()                                                     // 2: K loop done
 
     // ---- epilogue: two passes of 64 samples (row blocks 2*half, 2*half + 1 of the accumulators) ------
     const float oscale = wi * hi;
@@ -747,6 +763,7 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
                 }
         }
         __syncthreads();
+        XSTAMP()                                                 // 3 / 5: accumulators dropped into the LDS tile
         float lsum = 0.f;                            // lane = sample row of the pass, wave-uniform feature
         const int r = half * XHR + lane;
         // a wave's (up to) three features of the pass in one straight-line block: the evaluations are
@@ -767,11 +784,14 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
                 if (f < fv) {
                     xs[r * fpt + f] = yv[u];
                     lsum += ld[u];
+#ifndef NF_STAMP
                     if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + f] = bin[u];
+#endif
                 }
             }
         }
         ldp[wc * XM + r] = lsum;
+        XSTAMP()                                                 // 4 / 6: splines of the pass evaluated
     }
     __syncthreads();
     if (tid < XM) {
@@ -797,6 +817,17 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
         //  of same-address atomics per launch would queue up in L2)
         if (lane == 0 && __float_as_uint(ymax) > __builtin_nontemporal_load(g.out_max)) atomicMax(g.out_max, __float_as_uint(ymax));
     }
+#ifdef NF_STAMP
+    XSTAMP()                                                     // 7: outputs stored
+    if (g.bins && lane == 0) {
+        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * (XT / 64) + wc) * 16;
+        for (int i = 0; i < 8; ++i) dbg[i] = sp[i];
+        dbg[8] = g.ktab[2 * tn + 1] - g.ktab[2 * tn];
+        dbg[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        dbg[10] = tn;
+    }
+#endif
+#undef XSTAMP
 }
 
 // Hidden-layer GEMM on split operands: y = [relu](x) @ (W * mask)^T + b (+ residual) [relu], fp32 in and out,
@@ -1256,9 +1287,312 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
+
+// ======================================================================================================
+// Eight-wave flavour of the f16x2 fused layer (whole-layer launches with the hidden state pre-split).
+//
+// Why: in the four-wave kernel above a wave owns a 128 x 64 accumulator (244 VGPRs), so a CU holds two waves per
+// SIMD and nothing is left to hide the K loop's per-step bubbles (LDS read latency and the barrier in front of every
+// 768-cycle MFMA block: 1280 clocks per step measured with one workgroup per CU, 1540-1640 with two) or to run one
+// workgroup's spline epilogue under another's MFMAs (matrix pipe 47 % busy).  Here a workgroup is 512 threads on the
+// same 128 x 256 tile, a wave owns 64 x 64 (64 accumulator VGPRs, < 128 in all) and a CU holds FOUR waves per SIMD
+// from two workgroups; both operands go global -> LDS by LDS-DMA (no staging registers, no ds_write, no VALU in the
+// loop), three 24 KB stages deep, one raw s_barrier per 16-wide K step with a counted vmcnt in front of it:
+//   wait own pieces of step k | barrier | issue pieces of step k+2 | 8 ds_read_b128 | 12 MFMA
+// The LDS image of a stage is lane-linear per 1 KB piece (what an LDS-DMA instruction writes): the A pieces come
+// from the "tiled planes" the pre-pass writes ([row tile][step][term][slot][8 halfs], the conflict-free half swap
+// already applied), the B pieces are the packed weights as they are ([tile][step][wave][j][term][lane][8]).
+constexpr int YT = 512, YM = 128;
+constexpr int YA_BYTES = 2 * YM * XS * 2;          // A of one K step: 2 term planes x 128 rows x 16 halfs (8 KB)
+constexpr int YB_BYTES = 2 * FN * XS * 2;          // B of one K step: 2 term planes x 256 columns x 16 halfs (16 KB)
+constexpr int YSTAGE = YA_BYTES + YB_BYTES;
+#ifndef NF_YNS
+#define NF_YNS 3
+#endif
+#ifndef NF_YA_HINT
+#define NF_YA_HINT ""
+#endif
+#ifndef NF_YB_HINT
+#define NF_YB_HINT ""
+#endif
+constexpr int YNS = NF_YNS;
+
+// one LDS-DMA wave-instruction: lane l's 16 (4) bytes at gsrc land at lds_dst + 16 l (4 l); lds_dst wave-uniform.
+// M0 is compiler-reserved: saved and restored around the instruction.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" NF_YA_HINT "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds16b(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" NF_YB_HINT "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+constexpr int YFP = 4;                               // features per epilogue pass: 8 waves = 4 features x 2 row halves
+constexpr int YLDT = YM + 4;                         // column-major parameter tile of a pass: [4 P columns][128 + 4]
+__host__ __device__ inline int w8_ring_bytes(int P) {
+    const int tile = YFP * P * YLDT * 4;             // epilogue tile (aliases the stages)
+    return (tile > YNS * YSTAGE ? tile : YNS * YSTAGE + 15) / 16 * 16;
+}
+__host__ __device__ inline int w8_xs_bytes(int fpt) { return (YM * fpt + 63) / 64 * 256; }   // whole 64-element DMA pieces
+
+__device__ __forceinline__ void wait_vmcnt(int n) {          // counted wait with a wave-uniform runtime count
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    }
+}
+
+template <int KT, bool INV>
+__global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArgs g) {
+    typedef SplitF16x2 SP;
+    typedef SP::vec vec;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int fpt = g.fpt, P = g.c.P;
+    const int ring = w8_ring_bytes(P);
+    float* tile = (float*)lds;                               // epilogue: [4 P][YLDT], aliases the stages
+    float* xs = (float*)(lds + ring);                        // [128][fpt] inputs, overwritten by outputs
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    int64_t tm;
+    int tn;
+    tile_of_block(g, tm, tn);
+    const int64_t m0 = tm * YM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wq = w & 3;
+    const int f0 = tn * fpt;
+    const int fv = min(fpt, g.feat_limit - f0);
+#ifdef NF_STAMP
+    long long sp_[12], t_dma = 0, t_bar = 0;
+    int spn = 0;
+#define YSTAMP() { __builtin_amdgcn_sched_barrier(0); sp_[spn++] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define YSTAMP()
+#endif
+    YSTAMP()
+
+    const int ksteps = (g.K + XS - 1) / XS;
+    const int kt_begin = g.ktab[2 * tn];
+    const int kt_end = min(g.ktab[2 * tn + 1], ksteps);
+
+    // per step a wave moves A piece w (of 8) and B pieces w, w + 8 (of 16)
+    const char* asrc = (const char*)g.hp + ((int64_t)tm * (g.hp_ld / XS)) * YA_BYTES + w * 1024 + lane * 16;
+    const char* bsrc = (const char*)g.w + ((int64_t)tn * (g.kpad / XS)) * YB_BYTES + w * 1024 + lane * 16;
+    auto issue = [&](int kt, int st) {
+        if (NF_KO_LOADS) return;
+        const unsigned dst = lds_base + st * YSTAGE + w * 1024;
+        glds16(asrc + (int64_t)kt * YA_BYTES, dst);
+        glds16b(bsrc + (int64_t)kt * YB_BYTES, dst + YA_BYTES);
+        glds16b(bsrc + (int64_t)kt * YB_BYTES + 8192, dst + YA_BYTES + 8192);
+    };
+#pragma unroll
+    for (int q = 0; q < YNS - 1; ++q)
+        if (kt_begin + q < kt_end) issue(kt_begin + q, q);
+    const int pro = min(YNS - 1, max(kt_end - kt_begin, 0));       // K steps the prologue issued
+
+    // inputs of the tile, straight into LDS (4-byte LDS-DMA, 64 elements per piece), BEHIND the first stages: they are
+    // first read in the epilogue, so they must not hold up the first K steps (loads retire in order)
+    int nxp = 0;                                                   // pieces this wave issued
+    {
+        const int nx = YM * fpt;
+        for (int pc = w; pc * 64 < nx; pc += YT / 64) {
+            const int i = min(pc * 64 + lane, nx - 1);
+            const int r = i / fpt, f = min(i - r * fpt, fv - 1);
+            const int64_t row = min(m0 + r, g.M - 1);
+            glds4(g.x + row * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f), lds_base + ring + pc * 256);
+            ++nxp;
+        }
+    }
+    // the bias joins in the epilogue (its load would otherwise sit in front of the first MFMA), the accumulators start at 0
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[j] = g.bias[tn * FN + wq * 64 + j * 32 + (lane & 31)];
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment offsets inside a stage
+    const int frow = lane & 31;
+    const int aoff = ((wr * 64 + frow) * 2 + ((lane >> 5) ^ ((frow >> 3) & 1))) * 16;      // + i * 1024 + p * 4096
+    const int boff = YA_BYTES + wq * 4096 + lane * 16;                                     // + (j * 2 + p) * 1024
+    YSTAMP()
+
+    int st = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        // own pieces of step kt landed; what was issued after them may stay in flight: the later steps' pieces (3 each)
+        // and, while the prologue's steps are being consumed, the input pieces issued behind the prologue
+        const int later = min(YNS - 2, kt_end - 1 - kt);
+#ifdef NF_STAMP
+        const long long q0 = clock64();
+#endif
+        wait_vmcnt(3 * later + (kt - kt_begin < pro ? nxp : 0));
+#ifdef NF_STAMP
+        const long long q1 = clock64();
+#endif
+        // ... and everybody's: after the barrier stage st is complete and nobody reads stage st - 1 any more
+        __builtin_amdgcn_s_barrier();
+#ifdef NF_STAMP
+        t_dma += q1 - q0;
+        t_bar += clock64() - q1;
+#endif
+        if (kt + YNS - 1 < kt_end) issue(kt + YNS - 1, st == 0 ? YNS - 1 : st - 1);
+        const char* sp = lds + st * YSTAGE;
+        vec a[2][2], b[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p_ = 0; p_ < 2; ++p_) b[j][p_] = *reinterpret_cast<const vec*>(sp + boff + (j * 2 + p_) * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p_ = 0; p_ < 2; ++p_) a[i][p_] = *reinterpret_cast<const vec*>(sp + aoff + i * 1024 + p_ * 4096);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!NF_KO_MMA) SP::fma_tile(acc[i][j], a[i], b[j]);
+                else acc[i][j][0] += (float)a[i][0][0] + (float)b[j][1][1];          // (keeps the fragment reads alive)
+            }
+        st = st == YNS - 1 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the inputs' DMA when there was no K step at all)
+    YSTAMP()
+
+    // ---- epilogue: passes of 4 features x all 128 samples; every wave hands over the columns it holds of the pass's
+    //      features, then evaluates ONE (feature, row half) - the same amount of spline work in every wave -------------
+    float ws = 1.f, wi = 1.f, hs = 1.f, hi = 1.f;
+    pow2_pair(*g.wmax, ws, wi);
+    pow2_pair(*g.hmax, hs, hi);
+    const float oscale = wi * hi;
+    const int r = (w & 1) * 64 + lane;                       // this lane's sample row in every pass
+    float lsum = 0.f;
+#pragma unroll 1
+    for (int f_pass = 0; f_pass < fv; f_pass += YFP) {
+        const int c0 = f_pass * P, c1 = min(f_pass + YFP, fpt) * P;
+        __syncthreads();                                     // stages / previous pass fully consumed
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wq * 64 + j * 32 + (lane & 31);
+            if (col >= c0 && col < c1) {
+                float* tp = tile + (col - c0) * YLDT + wr * 64 + 4 * (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                        v.x = v.x * oscale + bv[j]; v.y = v.y * oscale + bv[j];
+                        v.z = v.z * oscale + bv[j]; v.w = v.w * oscale + bv[j];
+                        *reinterpret_cast<float4*>(tp + i * 32 + 8 * q) = v;
+                    }
+            }
+        }
+        __syncthreads();
+        const int fl = w >> 1, f = f_pass + fl;              // wave-uniform feature of this wave
+        if (f < fv) {
+            float yv, ld;
+            int bin;
+            if (NF_KO_EVAL) { yv = tile[fl * P * YLDT + r]; ld = yv; bin = 0; }
+            else rqs_eval<KT, INV, YLDT, true, true, const float*, false>(tile + fl * P * YLDT + r, xs[r * fpt + f], g.c, yv, ld, bin);
+            xs[r * fpt + f] = yv;
+            lsum += ld;
+#ifndef NF_STAMP
+            if (g.bins && m0 + r < g.M) g.bins[(m0 + r) * (int64_t)g.D + f0 + f] = bin;
+#endif
+        }
+    }
+    YSTAMP()
+    __syncthreads();
+    float* ldp = tile;                                       // [4 feature slots][128]: the tile is dead now
+    ldp[(w >> 1) * YM + r] = lsum;
+    __syncthreads();
+    if (tid < YM) {
+        const float s = ((ldp[tid] + ldp[YM + tid]) + ldp[2 * YM + tid]) + ldp[3 * YM + tid];      // fixed order
+        if (m0 + tid < g.M) g.partial[(int64_t)tn * g.M + m0 + tid] = s;
+    }
+    float ymax = 0.f;
+    for (int i = tid; i < YM * fpt; i += YT) {
+        const int rr = i / fpt, f = i - rr * fpt;
+        if (m0 + rr < g.M && f < fv) {
+            const float v = xs[i];
+            g.y[(m0 + rr) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = v;
+            const float a = fabsf(v);
+            ymax = fmaxf(ymax, a < INFINITY ? a : 0.f);
+        }
+    }
+    if (g.out_max) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+        if (lane == 0 && __float_as_uint(ymax) > __builtin_nontemporal_load(g.out_max)) atomicMax(g.out_max, __float_as_uint(ymax));
+    }
+#ifdef NF_STAMP
+    YSTAMP()
+    if (g.bins && lane == 0) {
+        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * (YT / 64) + w) * 16;
+        for (int i = 0; i < 5; ++i) dbg[i] = sp_[i];
+        dbg[8] = kt_end - kt_begin;
+        dbg[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        dbg[10] = tn;
+        dbg[11] = t_dma;
+        dbg[12] = t_bar;
+    }
+#endif
+#undef YSTAMP
+}
+
+// h[M][K] fp32 -> the eight-wave kernel's A stream: [row tile of 128][K step][term][slot][8 halfs], slot = 2 * row +
+// (k half ^ bit 3 of the row): one K step of one row tile is 8 KB, contiguous, already in its LDS image order
+template <class SP>
+__global__ __launch_bounds__(256) void split_planes_tiled_kernel(const float* __restrict__ h, int64_t ldh, int64_t M,
+                                                                 int K, int ksteps, const unsigned* __restrict__ hmax,
+                                                                 typename SP::elem* __restrict__ planes) {
+    float hs = 1.f, hi = 1.f;
+    if (SP::SCALED) pow2_pair(*hmax, hs, hi);
+    const int cpr = ksteps * 2;                                // 8-element chunks per row
+    const int64_t rows = (M + YM - 1) / YM * YM;
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int c = (int)(i - row * cpr);
+        const int kt = c >> 1, half = c & 1, k = c * 8;
+        const bool live = row < M && k < K;                    // K % 8 == 0: a chunk is wholly in or out
+        const float* p = h + (live ? row * ldh + k : 0);
+        typename SP::vec t[SP::NT];
+        split_chunk<SP>(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), live, hs, t);
+        const int rl = (int)(row & (YM - 1));
+        const int slot = rl * 2 + (half ^ ((rl >> 3) & 1));
+        typename SP::elem* o = planes + (((row >> 7) * ksteps + kt) * SP::NT * (2 * YM) + slot) * 8;
+#pragma unroll
+        for (int q = 0; q < SP::NT; ++q) *reinterpret_cast<typename SP::vec*>(o + q * (2 * YM) * 8) = t[q];
+    }
+}
+
 inline int split_terms(int dtype) { return dtype == NF_DTYPE_BF16X3 ? 3 : dtype == NF_DTYPE_F16X2 ? 2 : 0; }
 inline int kp16_of(int in) { return (in + XS - 1) / XS * XS; }
-inline size_t planes_bytes(int64_t B, int in, int dtype) { return (size_t)split_terms(dtype) * (size_t)B * kp16_of(in) * 2; }
+// (rows rounded up to whole 128-row tiles: the tiled layout of the eight-wave kernel)
+inline size_t planes_bytes(int64_t B, int in, int dtype) {
+    return (size_t)split_terms(dtype) * (size_t)((B + YM - 1) / YM * YM) * kp16_of(in) * 2;
+}
 
 inline size_t lds_bytes_split(int fpt, int P, int nt) {
     const size_t tile = sizeof(float) * (size_t)fpt * P * XLDT;
@@ -1285,6 +1619,25 @@ int launch_k_split(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
     }
 }
 
+template <int KT, bool INV>
+int launch_one_w8(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+    static unsigned long long cap_done = 0;
+    const int rc = nf_raise_lds_cap((const void*)made_rqs_f16x2_w8_kernel<KT, INV>, &cap_done);
+    if (rc != NF_OK) return rc;
+    hipLaunchKernelGGL((made_rqs_f16x2_w8_kernel<KT, INV>), dim3(grid), dim3(YT), lds, s, g);
+    return nf_launch_status();
+}
+
+template <bool INV>
+int launch_k_w8(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+    switch (g.c.K) {
+        case 4: return launch_one_w8<4, INV>(g, grid, lds, s);
+        case 8: return launch_one_w8<8, INV>(g, grid, lds, s);
+        case 10: return launch_one_w8<10, INV>(g, grid, lds, s);
+        default: return launch_one_w8<0, INV>(g, grid, lds, s);
+    }
+}
+
 // the split pre-pass (when the workspace has room for the planes and the launch covers the layer) + the kernel
 inline int maxabs_rows(const float* h, int64_t ld, int64_t B, int cols, unsigned* slot, hipStream_t s) {
     hipError_t me = hipMemsetAsync(slot, 0, sizeof(unsigned), s);
@@ -1301,6 +1654,16 @@ int run_split(FusedArgs& g, int grid, size_t lds, bool pre, bool own_max, const 
     if (SP::SCALED && own_max) {                       // no producer left max |h| in the slot: find it
         const int rc = maxabs_rows(h, h_row_stride, B, in, const_cast<unsigned*>(g.hmax), s);
         if (rc != NF_OK) return rc;
+    }
+    if (pre && SP::NT == 2 && w8_ring_bytes(g.c.P) + w8_xs_bytes(g.fpt) <= 160 * 1024) {
+        // f16x2, whole layer: tiled planes + the eight-wave kernel
+        const int ksteps = (int)(g.hp_ld / XS);
+        const int64_t chunks = (B + YM - 1) / YM * YM * ksteps * 2;
+        const int sgrid = (int)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
+        hipLaunchKernelGGL(split_planes_tiled_kernel<SplitF16x2>, dim3(sgrid), dim3(256), 0, s, h, h_row_stride, B, in,
+                           ksteps, g.hmax, (_Float16*)g.hp);
+        const size_t lds8 = (size_t)w8_ring_bytes(g.c.P) + w8_xs_bytes(g.fpt);
+        return inverse ? launch_k_w8<true>(g, grid, lds8, s) : launch_k_w8<false>(g, grid, lds8, s);
     }
     if (pre) {
         const int64_t chunks = B * (g.hp_ld / 8);

@@ -41,6 +41,81 @@ def sharded_log_prob(log_prob_fn, x_global, group=None):
     return lp, lo, hi, (s / n if n else float('nan'))
 
 
+def _rank_world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def streamed_log_likelihood(log_prob_fn, n_global, make_rows, rows_per_pass, group=None):
+    """BASELINE.json configs[3] (batch far larger than memory, e.g. 64 M x 784 = 200 GB of inputs): this rank's
+    contiguous shard [lo, hi) of `n_global` rows is produced `rows_per_pass` rows at a time by `make_rows(s, e)` (a
+    device-side generator, or a slice of a memory-mapped file: nothing of size [shard, D] is ever resident), pushed
+    through `log_prob_fn`, and only an fp64 [sum log p, count] pair survives a pass.  One all-reduce(SUM) of that pair
+    at the end is the whole exchange.  The last pass of a shard may be short; shards differ by at most one row.
+    Returns (sum over all ranks, count over all ranks, this rank's (lo, hi))."""
+    if rows_per_pass <= 0:
+        raise ValueError('rows_per_pass must be positive')
+    rank, world = _rank_world(group)
+    lo, hi = shard_bounds(n_global, rank, world)
+    acc = None
+    for s in range(lo, hi, rows_per_pass):
+        e = min(hi, s + rows_per_pass)
+        lp = log_prob_fn(make_rows(s, e))
+        if lp.shape[0] != e - s:
+            raise ValueError('log_prob_fn returned %d values for %d rows' % (lp.shape[0], e - s))
+        if acc is None:
+            acc = torch.zeros(2, dtype=torch.float64, device=lp.device)
+        acc[0] += lp.double().sum()
+        acc[1] += e - s
+    if acc is None:                                     # an empty shard still takes part in the reduction
+        acc = torch.zeros(2, dtype=torch.float64, device=_reduce_device(group))
+    if world > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    total, count = acc.tolist()
+    return total, count, (lo, hi)
+
+
+def streamed_sampling(sample_fn, n_global, rows_per_pass, group=None):
+    """The sampling half of configs[3]: this rank draws its shard of `n_global` samples `rows_per_pass` at a time with
+    `sample_fn(n) -> (x [n, D], log q [n])` (distributions.sample_and_log_prob); samples stay on the rank that drew
+    them (or are consumed there) and only fp64 moments cross ranks: one all-reduce(SUM) of
+    [count, sum log q, sum_b x (D values), sum_b x^2 (D values)].
+    Returns dict(count, mean_logq, mean [D], var [D]) over all ranks."""
+    if rows_per_pass <= 0:
+        raise ValueError('rows_per_pass must be positive')
+    rank, world = _rank_world(group)
+    lo, hi = shard_bounds(n_global, rank, world)
+    acc = None
+    for s in range(lo, hi, rows_per_pass):
+        n = min(hi, s + rows_per_pass) - s
+        x, logq = sample_fn(n)
+        x64 = x.double().reshape(n, -1)
+        part = torch.cat([torch.tensor([float(n)], dtype=torch.float64, device=x.device), logq.double().sum().reshape(1),
+                          x64.sum(0), (x64 * x64).sum(0)])
+        acc = part if acc is None else acc + part
+    if world > 1:
+        # every rank must agree on the vector's length: ranks with an empty shard learn it from the others
+        size = torch.tensor([0 if acc is None else acc.numel()], dtype=torch.int64, device=_reduce_device(group))
+        dist.all_reduce(size, op=dist.ReduceOp.MAX, group=group)
+        if acc is None:
+            acc = torch.zeros(int(size.item()), dtype=torch.float64, device=size.device)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    if acc is None or acc[0].item() == 0:
+        return {'count': 0.0, 'mean_logq': float('nan'), 'mean': None, 'var': None}
+    cnt = acc[0].item()
+    D = (acc.numel() - 2) // 2
+    mean = acc[2:2 + D] / cnt
+    return {'count': cnt, 'mean_logq': acc[1].item() / cnt, 'mean': mean, 'var': acc[2 + D:] / cnt - mean * mean}
+
+
+def _reduce_device(group=None):
+    """Device collectives of this group run on: the current GPU under RCCL, the CPU under gloo."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
 def allreduce_gradients(parameters, group=None, bucket_bytes=64 << 20, average=True):
     """Data-parallel gradient synchronisation: gradients are flattened into buckets of ~`bucket_bytes`
     and each bucket is all-reduced (SUM) asynchronously, then scaled by 1/world and copied back.

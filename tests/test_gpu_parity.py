@@ -792,6 +792,63 @@ def test_maf_legacy_fp64_golden(nf, D):
             assert rel_err(r.cpu(), fx['l%d/rev_z' % j]) < 1e-11 and rel_err(lj.cpu(), fx['l%d/rev_logJ' % j]) < 1e-11
 
 
+@pytest.mark.parametrize('mode', ['f32', 'f16x2'])
+def test_cfg4_streamed_log_likelihood_and_sampling(nf, mode):
+    """BASELINE.json configs[3] on one GPU (world 1; the two-rank reduction runs under gloo in test_parallel.py):
+    parallel.streamed_log_likelihood pushes a shard through the flow in passes of `rows_per_pass` rows with a short
+    last pass, the transforms' own launch groups (CHUNK_ROWS) forced small so that every pass is itself split
+    unevenly; the [sum, count] it returns is the oracle's over the same rows.  streamed_sampling draws the same
+    amount through the inverse and its moments are those of the samples it produced."""
+    from normalizing_flows_amd import parallel, transforms
+    D, H, K, Tb, L = 48, 96, 8, 3.0, 2
+    sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=60 + j) for j in range(L)]
+    flow = nf.BaseNeuralSplineFlow(nf.CompositeTransform(_load_layers(nf, sds, D, H, K, Tb)),
+                                   nf.StandardNormal([D])).cuda().eval()
+    n, rows_per_pass = 1000, 192                                 # 5 full passes + one of 40 rows
+    x = torch.randn(n, D, generator=torch.Generator().manual_seed(8))
+    xd = x.cuda()
+    buf = torch.empty(rows_per_pass, D, device='cuda')           # the resident staging buffer of a streamed run
+    seen = []
+
+    def make_rows(s, e):
+        seen.append((s, e))
+        buf[:e - s].copy_(xd[s:e])                               # (a device generator in bench.py; data here)
+        return buf[:e - s]
+
+    old_chunk = transforms.CHUNK_ROWS
+    transforms.CHUNK_ROWS = 80                                   # 192 -> 80 + 80 + 32, 40 -> 40
+    nf.set_matmul_dtype(mode)
+    try:
+        with torch.no_grad():
+            total, count, span = parallel.streamed_log_likelihood(flow.log_prob, n, make_rows, rows_per_pass)
+            gen = torch.Generator(device='cuda').manual_seed(5)
+            flow._distribution.generator = gen
+            drawn = []
+
+            def sample(m):
+                xs, lq = flow.sample_and_log_prob(m)
+                drawn.append((xs.clone(), lq.clone()))
+                return xs, lq
+
+            st = parallel.streamed_sampling(sample, 300, 128)
+    finally:
+        transforms.CHUNK_ROWS = old_chunk
+        nf.set_matmul_dtype('f32')
+    assert span == (0, n) and count == n and seen[-1] == (960, 1000) and len(seen) == 6
+    want = O.flow_log_prob([lambda v, s=s: O.rq_autoregressive_forward(
+        {k: (t.double() if t.is_floating_point() else t) for k, t in s.items()}, v, K, Tb) for s in sds], x.double())
+    assert abs(total - want.sum().item()) < 1e-5 * abs(want.sum().item())
+    xs = torch.cat([d[0] for d in drawn]).double().cpu()
+    lq = torch.cat([d[1] for d in drawn]).double().cpu()
+    assert [d[0].shape[0] for d in drawn] == [128, 128, 44] and st['count'] == 300
+    assert abs(st['mean_logq'] - lq.mean().item()) < 1e-9 * abs(lq.mean().item())
+    assert (st['mean'].cpu() - xs.mean(0)).abs().max() < 1e-9 and (st['var'].cpu() - xs.var(0, unbiased=False)).abs().max() < 1e-9
+    # log q of a sample = the density log_prob assigns to it (sampling and density directions agree)
+    with torch.no_grad():
+        back = flow.log_prob(torch.cat([d[0] for d in drawn]))
+    assert rel_err(back.cpu(), lq) < 2e-4
+
+
 def _legacy_layers(nf, fx, final=False):
     sfx = '_final' if final else ''
     layers = []

@@ -86,3 +86,61 @@ def test_two_rank_gradient_allreduce(tmp_path):
     assert got['buckets'] >= 2                      # several buckets in flight
     for i, g in enumerate(got['grads']):
         assert torch.allclose(g, torch.full_like(g, 1.5 * (i + 1)))      # mean of ranks' (1, 2) x (i+1)
+
+
+def _stream_worker(rank, world, port, n, rows_per_pass, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from normalizing_flows_amd import parallel
+        from oracle import nf_oracle as O
+        torch.set_num_threads(2)
+        D, H, K = 12, 24, 4
+        sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=7)
+        x = torch.randn(n, D, generator=torch.Generator().manual_seed(3))
+        passes = []
+
+        def make_rows(s, e):
+            passes.append((s, e))
+            return x[s:e]
+
+        def log_prob(v):
+            return O.flow_log_prob([lambda u: O.rq_autoregressive_forward(sd, u, K, 3.0)], v)
+
+        total, count, span = parallel.streamed_log_likelihood(log_prob, n, make_rows, rows_per_pass)
+        gen = torch.Generator().manual_seed(100 + rank)
+
+        def sample(m):
+            z = torch.randn(m, 3, generator=gen) * 2.0 + 1.0
+            return z, -z.pow(2).sum(1)
+
+        st = parallel.streamed_sampling(sample, n, rows_per_pass)
+        torch.save({'total': total, 'count': count, 'span': span, 'passes': passes, 'st_count': st['count'],
+                    'st_mean': st['mean'], 'st_var': st['var'], 'st_logq': st['mean_logq']}, out % rank)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n,rows_per_pass', [(101, 16), (5, 64), (1, 8)])
+def test_two_rank_streamed_log_likelihood(tmp_path, n, rows_per_pass):
+    """cfg-4's loop (parallel.streamed_log_likelihood) on two gloo ranks: shards streamed in short passes with a
+    ragged last pass (and, for n = 1, an EMPTY shard on rank 1) reduce to the single-process sum."""
+    from oracle import nf_oracle as O
+    out = str(tmp_path / 's%d.pt')
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_stream_worker, args=(2, port, n, rows_per_pass, out), nprocs=2, join=True)
+    got = [torch.load(out % r) for r in range(2)]
+    D, H, K = 12, 24, 4
+    sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=7)
+    x = torch.randn(n, D, generator=torch.Generator().manual_seed(3))
+    want = O.flow_log_prob([lambda u: O.rq_autoregressive_forward(sd, u, K, 3.0)], x).double().sum().item()
+    for r in range(2):
+        assert got[r]['count'] == n and abs(got[r]['total'] - want) < 1e-6 * max(1.0, abs(want))
+        lo, hi = got[r]['span']
+        assert got[r]['passes'] == [(s, min(hi, s + rows_per_pass)) for s in range(lo, hi, rows_per_pass)]
+        assert got[r]['st_count'] == n
+    assert got[0]['span'][1] == got[1]['span'][0] and got[1]['span'][1] == n
+    assert torch.equal(got[0]['st_mean'], got[1]['st_mean']) and got[0]['st_mean'].shape == (3,)
+    if n > 50:
+        assert (got[0]['st_mean'] - 1.0).abs().max() < 1.0 and (got[0]['st_var'] - 4.0).abs().max() < 2.5
