@@ -40,11 +40,12 @@ D, H, K, T, L = 784, 512, 8, 3.0, 5
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
-# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE doubled as the
-# microarch guide prescribes for gfx950, + WRITE_SIZE), collected separately: profiles/r01_j_f16x2_pmc.txt
-# (f32 mode: profiles/r01_h_f32_fused64_pmc.txt).
+# HBM-side bytes per launch of the dominant kernel.  NOT measured by this run: they come from separate rocprofv3 --pmc
+# passes over the same command (FETCH_SIZE doubled as the microarch guide prescribes for gfx950, + WRITE_SIZE), whose
+# summaries are committed under profiles/; the JSON line names the file next to the number (`traffic_source`).
 # Keyed by (dtype, fused kernel?, rows per launch); other shapes report null.
-TRAFFIC_BYTES_PER_LAUNCH = {('f32', True, 131072): 5.72e9, ('f16x2', True, 131072): 5.63e9}
+TRAFFIC_BYTES_PER_LAUNCH = {('f32', True, 131072): (5.72e9, 'profiles/r01_h_f32_fused64_pmc.txt'),
+                            ('f16x2', True, 131072): (5.67e9, 'profiles/r02_a_f16x2_pmc.txt')}
 DTYPE_LABEL = {'f32': 'f32', 'bf16': 'bf16-mfma/f32-accumulate',
                'bf16x3': 'f32 as 3 bf16 terms (6 bf16 MFMA per product, f32 accumulate)',
                'f16x2': 'f32 as 2 fp16 terms (3 fp16 MFMA per product, f32 accumulate)'}
@@ -74,6 +75,79 @@ def cpu_baseline(flow_cpu_sd, x_cpu, gpu_logp, reps):
             best = min(best, time.perf_counter() - t0)
     err = ((gpu_logp.double() - logp.double()).abs() / logp.double().abs().clamp_min(1.0)).max().item()
     return x_cpu.shape[0] / best, torch.get_num_threads(), err
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def roofline_block(kern, final, mode):
+    """The dominant kernel's roofline entry from the HIP-event launch times of one timed region (see module doc)."""
+    nnz = float(final.mask.sum().item())
+    key = [k for k in kern if k[0] in ('made_rqs', 'masked_linear') and k[2] == final.out_features]
+    if not key:
+        return None
+    fused = key[0][0] == 'made_rqs'
+    rows = key[0][3]
+    n, ms = kern[key[0]]
+    flop = 2.0 * nnz * rows
+    peak = PEAK_F32_MFMA_TFLOPS if mode == 'f32' else PEAK_BF16_MFMA_TFLOPS
+    ach = flop / (ms * 1e-3) / 1e12
+    mpp = MFMA_PER_PRODUCT[mode]
+    traffic = TRAFFIC_BYTES_PER_LAUNCH.get((mode, fused, rows), (None, None))
+    return {'bound': 'mfma',
+            'kernel': ('made_rqs kernel <%s> (final layer 512->18032 fused with the spline)' if fused
+                       else 'masked_linear_%s_kernel (final layer 512->18032)') % mode,
+            'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+            'mfma_flop_per_algorithmic_flop': mpp, 'executed_tflops': ach * mpp, 'executed_frac': ach * mpp / peak,
+            'achieved_over_fp32_matrix_peak': ach / PEAK_F32_MFMA_TFLOPS,
+            'traffic': traffic[0], 'traffic_source': traffic[1] and (traffic[1] + ' (separate rocprofv3 --pmc passes, not this run)'),
+            'launches': n, 'avg_launch_ms': ms, 'rows_per_launch': rows, 'algorithmic_flop_per_launch': flop,
+            'dense_equiv_tflops': 2.0 * final.out_features * final.in_features * rows / (ms * 1e-3) / 1e12}
+
+
+def two_moons_leg(nf, dev, steps):
+    """BASELINE.json configs[0] / north_star's two-moons figure: log-density of two-moons points under the 5-layer
+    legacy Gaussian MAF (float64, hidden 64; reference flows.py:230-263 through model.py:103-108), GPU kernels vs the
+    oracle on the host cores (bounded sample), checked against each other."""
+    import numpy as np
+    from oracle import nf_oracle as O
+    np.random.seed(5)
+    torch.manual_seed(5)
+    layers = torch.nn.ModuleList([nf.MaskedAutoregressiveFlow(2, [64], reverse_input=(j % 2 == 0)) for j in range(5)])
+    ref = [([l.weight.detach().clone() for l in f.made._linears()], [l.bias.detach().clone() for l in f.made._linears()],
+            [torch.as_tensor(m).double() for m in f.made.mask_matrix], bool(f.reverse_input)) for f in layers]
+    layers = layers.to(dev)
+    prior = nf.StandardNormal([2]).to(dev)
+    n = 1 << 20
+    x = nf.two_moons(n, torch.Generator(device=dev).manual_seed(77), device=dev)
+    with torch.no_grad():
+        lp = nf.apply_reverse_to_samples(layers, x, 0, prior)[1]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lp = nf.apply_reverse_to_samples(layers, x, 0, prior)[1]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        m = 1 << 16
+        xc = x[:m].cpu()
+        best = float('inf')
+        for _ in range(3):
+            t1 = time.perf_counter()
+            want = O.legacy_reverse_to_samples(ref, xc, 0)[1]
+            best = min(best, time.perf_counter() - t1)
+    err = ((lp[:m].cpu() - want).abs() / want.abs().clamp_min(1.0)).max().item()
+    return {'workload': 'cfg1: 5x MaskedAutoregressiveFlow(2, [64]) float64, log-density of two-moons points',
+            'value': n / dt, 'unit': 'samples/s (this rank)', 'batch': n, 'ms_per_step': 1e3 * dt, 'dtype': 'f64',
+            'cpu_baseline': {'value': m / best, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                             'sample': 'oracle on the first %d points, best of 3' % m},
+            'parity_max_rel_err_vs_oracle': err, 'mean_log_prob': lp.double().mean().item()}
 
 
 def main():
@@ -119,23 +193,21 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(4321 + rank)
     xbuf = torch.empty_like(x) if args.stream_total else None
 
+    last = {}
+
+    def make_rows(s, e):                     # cfg-4: the shard is produced pass by pass on the device
+        return xbuf[:e - s].normal_(generator=gen)
+
+    def log_prob_pass(xb):
+        last['logp'] = flow.log_prob(xb)
+        return last['logp']
+
     def step():
         if args.stream_total:
-            # cfg-4: the shard is produced group by group on the device; only per-group [sum, count] survive
-            acc = torch.zeros(2, dtype=torch.float64, device=dev)
-            done, logp = 0, None
+            # cfg-4 (parallel.streamed_log_likelihood): only an fp64 [sum, count] pair survives a pass; one all-reduce
             with torch.no_grad():
-                while done < args.stream_total:
-                    n = min(B, args.stream_total - done)
-                    xb = xbuf[:n].normal_(generator=gen)
-                    logp = flow.log_prob(xb)
-                    acc[0] += logp.double().sum()
-                    acc[1] += n
-                    done += n
-            if dist is not None:
-                dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-            s_, n_ = acc.tolist()
-            return logp, (s_, n_)
+                s_, n_, _ = parallel.streamed_log_likelihood(log_prob_pass, world * args.stream_total, make_rows, B)
+            return last['logp'], (s_, n_)
         with torch.no_grad():
             logp = flow.log_prob(x)
         # the log-likelihood reduction of the sharded batch: [sum, count] in fp64, one all-reduce
@@ -183,25 +255,9 @@ def main():
         }
         # dominant kernel: the final MADE layer (512 -> 18032)
         final = flow._transform._transforms[0].autoregressive_net.final_layer
-        nnz = float(final.mask.sum().item())
-        key = [k for k in kern if k[0] in ('made_rqs', 'masked_linear') and k[2] == final.out_features]
-        if key:
-            fused = key[0][0] == 'made_rqs' 
-            rows = key[0][3]
-            n, ms = kern[key[0]]
-            flop = 2.0 * nnz * rows
-            peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
-            ach = flop / (ms * 1e-3) / 1e12
-            mpp = MFMA_PER_PRODUCT[args.dtype]
-            out['roofline'] = {'bound': 'mfma',
-                               'kernel': ('made_rqs_kernel<%s> (final layer 512->18032 fused with the spline)' if fused
-                                          else 'masked_linear_%s_kernel (final layer 512->18032)') % args.dtype,
-                               'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                               'mfma_flop_per_algorithmic_flop': mpp, 'executed_tflops': ach * mpp,
-                               'executed_frac': ach * mpp / peak, 'achieved_over_fp32_matrix_peak': ach / PEAK_F32_MFMA_TFLOPS,
-                               'traffic': TRAFFIC_BYTES_PER_LAUNCH.get((args.dtype, fused, rows)), 'launches': n, 'avg_launch_ms': ms, 'rows_per_launch': rows,
-                               'algorithmic_flop_per_launch': flop,
-                               'dense_equiv_tflops': 2.0 * final.out_features * final.in_features * rows / (ms * 1e-3) / 1e12}
+        rb = roofline_block(kern, final, args.dtype)
+        if rb:
+            out['roofline'] = rb
         rq = [k for k in kern if k[0] == 'rqs']
         if rq:
             n, ms = kern[rq[0]]
@@ -220,16 +276,23 @@ def main():
                 nf.set_matmul_dtype(mode)
                 with torch.no_grad():
                     lpm = flow.log_prob(x)
+                tm = nf._lib.KernelTimer()
+                nf._lib.set_timer(tm)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(args.steps):
                     lpm, _ = step()
                 torch.cuda.synchronize()
                 dtm = time.perf_counter() - t1
+                nf._lib.set_timer(None)
                 out['other_modes'][mode] = {'value': B * args.steps / dtm, 'unit': 'samples/s (this rank)',
                                             'ms_per_step': 1e3 * dtm / args.steps, 'dtype': DTYPE_LABEL[mode],
                                             'max_rel_diff_vs_headline_log_prob':
-                                                ((lpm - logp).abs() / logp.abs().clamp_min(1.0)).max().item()}
+                                                ((lpm - logp).abs() / logp.abs().clamp_min(1.0)).max().item(),
+                                            'roofline': roofline_block(tm.summary(), final, mode)}
+                if mode == 'f32':
+                    # the reference's own arithmetic (every product an exact fp32 product): its roofline entry in full
+                    out['roofline_f32_mode'] = out['other_modes'][mode]['roofline']
             nf.set_matmul_dtype(args.dtype)
             # the other direction of the same flow: sample = transform.inverse(z) (reference distributions.py:192-193,
             # transforms.py:493-500: D conditioner passes per layer; here one row-resident launch per layer)
@@ -246,14 +309,23 @@ def main():
             out['inverse_sampling'] = {'value': ns / dts, 'unit': 'samples/s (this rank)', 'batch': ns,
                                        'roundtrip_max_abs_err': (zb - zs).abs().max().item(),
                                        'logdet_cancel_max_abs': (lds + ldb).abs().max().item()}
-        f32_tf, bf16_tf, copy_gbs = nf._lib.measure_device_peaks()
+        f32_tf, bf16_tf, copy_gbs, f16_rand_tf = nf._lib.measure_device_peaks()
         out['measured_device_peaks'] = {'mfma_f32_tflops': f32_tf, 'mfma_bf16_tflops': bf16_tf, 'copy_gbs': copy_gbs,
-                                        'note': 'back-to-back MFMA issue loop / 1 GiB float4 copy on this device; the '
+                                        'mfma_f16_random_operand_tflops': f16_rand_tf,
+                                        'note': 'back-to-back MFMA issue loops (fp32 / bf16 on constant operands; fp16 on '
+                                                'pseudo-random operands that change per instruction, 1 s sustained: what '
+                                                'the pipe holds under the board power cap on real data - '
+                                                'profiles/r02_power_trace.json) / 1 GiB float4 copy on this device; the '
                                                 'roofline fractions above use the nominal peaks'}
+        if 'roofline' in out and args.dtype != 'f32' and f16_rand_tf > 0:
+            out['roofline']['executed_frac_of_measured_random_operand_peak'] = out['roofline']['executed_tflops'] / f16_rand_tf
+        if world == 1 and not args.stream_total:
+            out['two_moons'] = two_moons_leg(nf, dev, max(args.steps, 3))
         if not args.no_cpu and world == 1:
             n = min(args.cpu_sample, B)
             v, cores, err = cpu_baseline(sd_cpu, x[:n].cpu(), logp[:n].cpu(), reps=3)
             out['cpu_baseline'] = {'value': v, 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+                                   'cpu_model': cpu_model(),
                                    'sample': 'oracle (reference ATen op sequence, fp32, torch CPU) on the first %d '
                                              'samples of rank 0, best of 3' % n}
             out['parity_max_rel_err_vs_oracle'] = err

@@ -1078,7 +1078,8 @@ def maf_reverse_step_bwd(x, made_out, grad_z_new, grad_logJ, dim, reverse_input)
 
 # ------------------------------------------------------------------------------------------------ diagnostics
 def measure_device_peaks(seconds_hint=0.05):
-    """(fp32-MFMA TFLOP/s, bf16-MFMA TFLOP/s, copy GB/s counting read+write) sustained by this device."""
+    """(fp32-MFMA TFLOP/s, bf16-MFMA TFLOP/s on constant operands, copy GB/s counting read+write, fp16-MFMA TFLOP/s on
+    pseudo-random operands) sustained by this device."""
     lib = load()
     scratch = torch.zeros(16, dtype=torch.float32, device='cuda')
     out = []
@@ -1105,4 +1106,18 @@ def measure_device_peaks(seconds_hint=0.05):
         torch.cuda.synchronize()
         best = max(best, 2 * n / (a.elapsed_time(b) * 1e-3) / 1e9)
     out.append(best)
+    # fp16 MFMA on pseudo-random, rotating operands, sustained for about a second (the power controller needs that
+    # long to settle): the rate the matrix pipe holds on real data under the board's power cap
+    blocks, iters = 256 * 4, 20000
+    flop = blocks * 4 * iters * 4 * 32768.0
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 160
+    for _ in range(reps // 2):
+        _check(lib.nf_diag_mfma_loop(scratch.data_ptr(), blocks, iters, NF_DTYPE_F16X2, _stream()), 'nf_diag_mfma_loop')
+    a.record()
+    for _ in range(reps // 2):
+        _check(lib.nf_diag_mfma_loop(scratch.data_ptr(), blocks, iters, NF_DTYPE_F16X2, _stream()), 'nf_diag_mfma_loop')
+    b.record()
+    torch.cuda.synchronize()
+    out.append((reps // 2) * flop / (a.elapsed_time(b) * 1e-3) / 1e12)
     return tuple(out)
