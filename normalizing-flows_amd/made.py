@@ -30,8 +30,11 @@ _default_matmul = 'f32'
 def set_matmul_dtype(name):
     """'f32' (exact fp32 MFMA, the 1e-5 contract), 'bf16' (bf16 MFMA, the 2e-2 contract), 'bf16x3' (the
     fused final layer on six bf16 MFMAs per product of three-term split fp32 operands: the 1e-5 contract) or
-    'f16x2' (three fp16 MFMAs per product of two-term split operands, weights power-of-two scaled: the 1e-5
-    contract while the hidden state stays below 1.3e5 in magnitude)."""
+    'f16x2' (three fp16 MFMAs per product of two-term split operands; weights scaled by a power of two at pack time,
+    the hidden state by one found per launch from its largest magnitude, so any finite range is taken: the 1e-5
+    contract holds for every element within 2^-14 of the launch's largest |h|; smaller ones keep 36 - log2(max/|h|)
+    bits - a hidden state with a 1e6 outlier unit still gives 1e-4, tests/test_gpu_parity.py::
+    test_f16x2_with_a_heavy_tailed_hidden_state)."""
     global _default_matmul
     if name not in _MATMUL_DTYPE:
         raise ValueError('matmul dtype must be one of %s' % sorted(_MATMUL_DTYPE))

@@ -629,6 +629,42 @@ def test_split_operand_modes_with_extreme_operand_ranges(nf, mode):
         assert (xi - x).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize('ratio,tol', [(1e4, 1e-5), (1e6, 1e-4)])
+def test_f16x2_with_a_heavy_tailed_hidden_state(nf, ratio, tol):
+    """The f16x2 operand scale is ONE power of two per launch, taken from the largest |h|: a hidden state with one
+    unit `ratio` times the rest is where max-scaled fp16 terms lose bits.  The outlier sits on the LAST hidden unit
+    (highest MADE degree: almost no output reads it, so it only costs the others their range).  An element keeps
+    its 22 bits while it is within 2^-14 of the largest one (ratio 1e4: the fp32 contract holds unchanged); below
+    that its low term goes subnormal and it keeps 36 - log2(ratio) bits (ratio 1e6: ~16 bits, 1e-4 here) - the
+    documented limit of this mode (made.set_matmul_dtype); the hidden-layer GEMM on the same operands likewise."""
+    from normalizing_flows_amd import _lib
+    D, H, K, Tb, B = 100, 64, 8, 3.0, 700
+    sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=23, scale=0.1)
+    w, m, b = (sd['autoregressive_net.final_layer.' + k] for k in ('weight', 'mask', 'bias'))
+    g = torch.Generator().manual_seed(4)
+    h = torch.randn(B, H, generator=g)
+    h[:, H - 1] *= ratio
+    x = torch.randn(B, D, generator=g) * 1.2
+    p64 = h.double() @ (w * m).double().t() + b.double()
+    y64, ld64 = O._rq_ar_elementwise(x.double(), p64, K, Tb, False, (1e-3, 1e-3, 1e-3))
+    y32, ld32 = O._rq_ar_elementwise(x, h @ (w * m).t() + b, K, Tb, False, (1e-3, 1e-3, 1e-3))
+    pf = _lib.PackedFusedFinal(w.cuda(), m.cuda(), b.cuda(), D, K, 'linear', _lib.NF_DTYPE_F16X2)
+    y, ld, _ = _lib.made_rqs(h.cuda(), pf, x.cuda(), Tb)
+    assert_close(y, y64, y32, tol=tol)
+    assert_close(ld, ld64, ld32, tol=tol)
+    # hidden-layer GEMM on the same operand
+    w2 = torch.randn(48, H, generator=g) * 0.1
+    m2 = ((torch.arange(48)[:, None] + 1) * H > torch.arange(H)[None, :] * 48).float()      # the last rows read unit H-1
+    pls = _lib.PackedLinearSplit(w2.cuda(), m2.cuda(), None, _lib.NF_DTYPE_F16X2)
+    got = _lib.masked_linear_split(h.cuda(), pls)
+    want = h.double() @ (w2 * m2).double().t()
+    seen = (m2[:, H - 1] > 0)                         # outputs that read the outlier are judged against its size
+    err = (got.cpu().double() - want).abs()
+    assert (err[:, ~seen] / want[:, ~seen].abs().clamp_min(1.0)).max().item() < tol
+    assert seen.any() and not seen.all()
+    assert (err[:, seen] / want[:, seen].abs().clamp_min(1.0)).max().item() < 1e-5
+
+
 # ------------------------------------------------------------------------------- affine / coupling
 def test_affine_ar_golden(nf):
     fx = load_golden('affine_ar')
