@@ -44,12 +44,15 @@ def main():
     opt = torch.optim.Adam(flow.parameters(), lr=1e-4)
     x = torch.randn(args.batch, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(99 + rank))
     losses = []
+    # gradients live in flat buckets; with several ranks their all-reduces start from per-parameter hooks while backward
+    # is still running (parallel.GradientSynchronizer); with one rank this only replaces the per-step zero_grad
+    sync = parallel.GradientSynchronizer(flow.parameters())
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        sync.zero_grad()
         loss = -flow.log_prob(x).mean()
         loss.backward()
-        parallel.allreduce_gradients(flow.parameters())
+        sync.finish()
         opt.step()
         return loss
 

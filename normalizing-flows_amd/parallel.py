@@ -9,6 +9,7 @@ when the batch is sharded.
 """
 import torch
 import torch.distributed as dist
+from torch import nn
 
 
 def shard_bounds(n, rank, world):
@@ -152,3 +153,178 @@ def allreduce_gradients(parameters, group=None, bucket_bytes=64 << 20, average=T
             g.copy_(flat[off:off + n].view_as(g))
             off += n
     return len(buckets)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Data-parallel training (BASELINE.json configs[4]): gradient all-reduce overlapped with backward, SyncBatchNorm
+# ---------------------------------------------------------------------------------------------------------------------
+class GradientSynchronizer:
+    """Bucketed gradient all-reduce that runs WHILE backward is still producing gradients.
+
+    The parameters' `.grad` tensors are views into a few flat, persistent bucket buffers (no per-step cat / copy
+    back).  Buckets are filled in reverse parameter order - the order backward reaches them - and a
+    post-accumulate-grad hook on every parameter counts its bucket down; when the last gradient of a bucket has been
+    written its all-reduce(SUM) is launched asynchronously, so the collectives of the last layers' buckets run on
+    RCCL's stream under the backward GEMMs of the earlier layers.  `finish()` waits for the collectives and scales by
+    1 / world.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few large buckets (64 MB default; the cfg-3
+    model has 214 MB of fp32 gradients) keep every ring busy without serialising behind one giant message.
+
+        sync = GradientSynchronizer(model.parameters())
+        for batch in shard:
+            sync.zero_grad()                  # zeroes the flat buffers in place (the views stay)
+            loss(batch).backward()            # all-reduces start as buckets complete
+            sync.finish()                     # gradients are now the mean over ranks
+            optimizer.step()
+
+    The reference has no counterpart (single process).  With world size 1 (or no process group) it only provides
+    the flat views and `finish()` is a no-op."""
+
+    def __init__(self, parameters, group=None, bucket_bytes=64 << 20, average=True):
+        self.group, self.average = group, average
+        self.params = [p for p in parameters if p.requires_grad]
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.buckets = []                 # [flat, [params], pending, work]
+        self._bucket_of = {}
+        cur, size = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= bucket_bytes:
+                self._make_bucket(cur)
+                cur, size = [], 0
+        if cur:
+            self._make_bucket(cur)
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def _make_bucket(self, params):
+        dtype, device = params[0].dtype, params[0].device
+        if any(p.dtype != dtype or p.device != device for p in params):
+            raise ValueError('parameters of one bucket must share dtype and device')
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=dtype, device=device)
+        off, views = 0, []
+        for p in params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        b = {'flat': flat, 'params': list(params), 'views': views, 'pending': len(params), 'work': None}
+        for p, v in zip(params, views):
+            self._bucket_of[p] = (b, v)
+            p.grad = v
+        self.buckets.append(b)
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b['flat'].zero_()
+            b['pending'], b['work'] = len(b['params']), None
+            for p, v in zip(b['params'], b['views']):
+                if p.grad is not v:
+                    p.grad = v
+
+    def _hook(self, p):
+        b, v = self._bucket_of[p]
+        if p.grad is not v:                   # something replaced the view (zero_grad(set_to_none=True) ...): restore it
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+        b['pending'] -= 1
+        if b['pending'] == 0 and self.world > 1:
+            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Waits for the bucket collectives (buckets whose hooks did not all fire - unused parameters - are reduced
+        here) and averages.  Returns the number of buckets that were reduced while backward was still running."""
+        early = 0
+        for b in self.buckets:
+            if self.world > 1:
+                if b['work'] is None:
+                    b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                else:
+                    early += 1
+        for b in self.buckets:
+            if b['work'] is not None:
+                b['work'].wait()
+                if self.average:
+                    b['flat'].div_(self.world)
+            b['pending'], b['work'] = len(b['params']), None
+        return early
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+
+
+class _SyncBatchNormFn(torch.autograd.Function):
+    """Training-mode batch normalisation over the GLOBAL batch: statistics from one all-reduce(SUM) of
+    [sum x, sum x^2, n] per feature, backward from one all-reduce(SUM) of [sum dy, sum dy*xhat]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        n_local = x.shape[0]
+        stats = torch.cat([x.sum(0), (x * x).sum(0), x.new_full((1,), float(n_local))])
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        F_ = x.shape[1]
+        n = stats[-1]
+        mean = stats[:F_] / n
+        var = (stats[F_:2 * F_] / n - mean * mean).clamp_min(0.0)          # biased, as F.batch_norm normalises with
+        invstd = torch.rsqrt(var + eps)
+        xhat = (x - mean) * invstd
+        ctx.save_for_backward(xhat, weight, invstd)
+        ctx.group, ctx.n = group, n
+        ctx.mark_non_differentiable(mean, var, n)
+        return xhat * weight + bias, mean, var, n
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv, _gn):
+        xhat, weight, invstd = ctx.saved_tensors
+        F_ = xhat.shape[1]
+        sums = torch.cat([gy.sum(0), (gy * xhat).sum(0)])
+        gb_local, gw_local = sums[:F_].clone(), sums[F_:].clone()         # parameter gradients stay LOCAL sums: the
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)      # gradient all-reduce adds them up like any other
+        n = ctx.n
+        gx = (gy - sums[:F_] / n - xhat * (sums[F_:] / n)) * (weight * invstd)
+        return gx, gw_local, gb_local, None, None
+
+
+class SyncBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d whose train()-mode statistics span every rank's shard (reference: plain BatchNorm1d over the one
+    process's whole batch, made.py:232-236 / resnet.py:22-26 - sharding the batch must not change what it computes).
+    Same parameters, buffers and state_dict keys; eval() mode and single-process runs are nn.BatchNorm1d itself."""
+
+    group = None
+
+    def forward(self, x):
+        if not (self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return super().forward(x)
+        if x.dim() != 2:
+            raise ValueError('expected 2D input (got {}D input)'.format(x.dim()))
+        y, mean, var, n = _SyncBatchNormFn.apply(x, self.weight, self.bias, self.eps, self.group)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                unbiased = var * (n / (n - 1).clamp_min(1.0))
+                self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                self.running_var.mul_(1 - m).add_(unbiased, alpha=m)
+        return y
+
+
+def convert_sync_batchnorm(module, group=None):
+    """Replaces every nn.BatchNorm1d inside `module` (MADE / ResidualNet blocks built with use_batch_norm=True) by a
+    SyncBatchNorm1d sharing its parameters and buffers; returns `module`."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, nn.BatchNorm1d) and not isinstance(child, SyncBatchNorm1d):
+            sbn = SyncBatchNorm1d(child.num_features, eps=child.eps, momentum=child.momentum, affine=child.affine,
+                                  track_running_stats=child.track_running_stats)
+            sbn.group = group
+            if child.affine:
+                sbn.weight, sbn.bias = child.weight, child.bias
+            if child.track_running_stats:
+                sbn.running_mean, sbn.running_var = child.running_mean, child.running_var
+                sbn.num_batches_tracked = child.num_batches_tracked
+            sbn.train(child.training)
+            if isinstance(module, nn.ModuleList):
+                module[int(name)] = sbn
+            else:
+                setattr(module, name, sbn)
+        else:
+            convert_sync_batchnorm(child, group)
+    return module

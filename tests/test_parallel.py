@@ -144,3 +144,91 @@ def test_two_rank_streamed_log_likelihood(tmp_path, n, rows_per_pass):
     assert torch.equal(got[0]['st_mean'], got[1]['st_mean']) and got[0]['st_mean'].shape == (3,)
     if n > 50:
         assert (got[0]['st_mean'] - 1.0).abs().max() < 1.0 and (got[0]['st_var'] - 4.0).abs().max() < 2.5
+
+
+def _dp_model(use_bn):
+    torch.manual_seed(11)
+    layers = [torch.nn.Linear(6, 16)]
+    if use_bn:
+        layers.append(torch.nn.BatchNorm1d(16, eps=1e-3))
+    layers += [torch.nn.ReLU(), torch.nn.Linear(16, 16)]
+    if use_bn:
+        layers.append(torch.nn.BatchNorm1d(16, eps=1e-3))
+    layers += [torch.nn.ReLU(), torch.nn.Linear(16, 4)]
+    return torch.nn.Sequential(*layers).double()
+
+
+def _dp_loss(model, x):
+    return (model(x) - x[:, :4].sin()).pow(2).sum(1).mean()
+
+
+def _dp_worker(rank, world, port, use_bn, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from normalizing_flows_amd import parallel
+        torch.set_num_threads(1)
+        model = parallel.convert_sync_batchnorm(_dp_model(use_bn)).train()
+        x = torch.randn(64, 6, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+        lo, hi = parallel.shard_bounds(64, rank, world)
+        sync = parallel.GradientSynchronizer(model.parameters(), bucket_bytes=1024)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        early = []
+        for _ in range(3):
+            sync.zero_grad()
+            _dp_loss(model, x[lo:hi]).backward()
+            early.append(sync.finish())
+            opt.step()
+        if rank == 0:
+            torch.save({'sd': model.state_dict(), 'early': early, 'buckets': len(sync.buckets)}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('use_bn', [False, True])
+def test_two_rank_data_parallel_steps_equal_the_single_process_steps(tmp_path, use_bn):
+    """Three Adam steps on 2 x 32 samples (gloo ranks; gradients through GradientSynchronizer's hook-driven bucket
+    all-reduces, BatchNorm through SyncBatchNorm1d) leave the weights, and the BatchNorm running statistics, where
+    three single-process steps on the 64 samples leave them (fp64)."""
+    out = str(tmp_path / 'dp.pt')
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, use_bn, out), nprocs=2, join=True)
+    got = torch.load(out)
+    model = _dp_model(use_bn).train()
+    x = torch.randn(64, 6, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    for _ in range(3):
+        opt.zero_grad()
+        _dp_loss(model, x).backward()
+        opt.step()
+    want = model.state_dict()
+    assert list(got['sd'].keys()) == list(want.keys())             # SyncBatchNorm1d keeps BatchNorm1d's keys
+    for k, v in want.items():
+        # a bias in front of a BatchNorm has an exactly zero gradient in exact arithmetic; what backward leaves there is
+        # rounding noise (1e-17), which Adam's g / (sqrt(v) + 1e-8) turns into steps of ~1e-11 whose direction differs
+        # between the two summation orders: those entries are compared at 1e-9 absolute instead
+        pre_bn_bias = use_bn and k in ('0.bias', '3.bias', '1.running_mean', '4.running_mean')    # (the means carry those biases)
+        assert torch.allclose(got['sd'][k].double(), v.double(), rtol=1e-9, atol=1e-9 if pre_bn_bias else 1e-11), \
+            (k, (got['sd'][k].double() - v.double()).abs().max().item())
+    assert got['buckets'] >= 2 and all(e >= 1 for e in got['early'])   # collectives started before backward returned
+
+
+def test_gradient_synchronizer_single_process_views():
+    """Without a process group the synchronizer only provides flat gradient views: backward accumulates in place,
+    zero_grad keeps the views, and a replaced .grad is folded back into its bucket."""
+    from normalizing_flows_amd import parallel
+    model = _dp_model(False)
+    sync = parallel.GradientSynchronizer(model.parameters(), bucket_bytes=512)
+    x = torch.randn(8, 6, dtype=torch.float64)
+    sync.zero_grad()
+    _dp_loss(model, x).backward()
+    assert sync.finish() == 0
+    ref = [p.grad.clone() for p in model.parameters()]
+    flat = torch.cat([b['flat'] for b in sync.buckets])
+    assert flat.abs().sum() > 0 and all(p.grad.data_ptr() == sync._bucket_of[p][1].data_ptr() for p in model.parameters())
+    model.zero_grad(set_to_none=True)                              # a caller that drops the views
+    _dp_loss(model, x).backward()
+    sync.finish()
+    for p, r in zip(model.parameters(), ref):
+        assert torch.equal(p.grad, r) and p.grad.data_ptr() == sync._bucket_of[p][1].data_ptr()
