@@ -325,6 +325,14 @@ int nf_affine_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_inde
                   float* y, int64_t y_row_stride, float* logabsdet, int accumulate,
                   int64_t B, int D, int inverse, void* stream);
 
+/* ---- base density joined with the flow's logdet (replaces distributions.py:105-107 `SimpleNormal.log_prob` + the
+ *      `log_prob + logabsdet` of distributions.py:154-157 and the `log_prob - logabsdet` of :173-186) ----------------- */
+
+/* out[b] = lad_scale * logabsdet[b] + sum_d (-z[b,d]^2/2 - log(2 pi)/2); logabsdet NULL = the density alone.  `out`
+ * may alias `logabsdet`.  Fixed-order reduction (deterministic). */
+int nf_std_normal_log_prob(const float* z, int64_t z_row_stride, const float* logabsdet, double lad_scale, float* out,
+                           int64_t B, int D, void* stream);
+
 /* ---- backward kernels (maximum-likelihood training; the reference differentiates the same op sequences
  *      with autograd: test2.py:127-135, model.py:233-244) ---------------------------------------------- */
 

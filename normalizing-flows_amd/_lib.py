@@ -62,6 +62,8 @@ _SIGNATURES = {
     'nf_affine_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
                                  _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_int,
                                  _c.c_int, _c.c_void_p]),
+    'nf_std_normal_log_prob': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_double, _c.c_void_p, _c.c_int64,
+                                          _c.c_int, _c.c_void_p]),
     'nf_affine_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
                                  _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p,
                                  _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
@@ -910,6 +912,20 @@ def affine(x, params, layout, inverse=False, feat_index=None, out=None, logabsde
         _check(lib.nf_affine_fwd(xp, xs, _ptr(feat_index), pp, ps, int(layout), yp, ys, logabsdet.data_ptr(),
                                  int(accumulate), B, D, int(inverse), _stream()), 'nf_affine_fwd')
     return out, logabsdet
+
+
+def std_normal_log_prob(z, logabsdet=None, lad_scale=1.0):
+    """[B] = lad_scale * logabsdet + log N(z; 0, I), one launch (z: [B, D] with contiguous rows)."""
+    lib = load()
+    _dev(z, 'noise')
+    zp, zs = _rows(z, 'noise')
+    B, D = z.shape
+    out = torch.empty(B, dtype=torch.float32, device=z.device)
+    lad = None if logabsdet is None else _dev(logabsdet.contiguous(), 'logabsdet')
+    with torch.cuda.device(z.device):
+        _check(lib.nf_std_normal_log_prob(zp, zs, _ptr(lad), float(lad_scale), out.data_ptr(), B, D, _stream()),
+               'nf_std_normal_log_prob')
+    return out
 
 
 def affine_bwd(x, params, layout, grad_y, grad_lad, inverse=False, feat_index=None, num_features=None):

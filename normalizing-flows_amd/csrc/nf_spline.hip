@@ -484,6 +484,44 @@ extern "C" int nf_rqs_fwd(const float* x, int64_t x_row_stride, const int32_t* f
     return inverse ? launch_rqs<true>(a, (int)grid, lds, s) : launch_rqs<false>(a, (int)grid, lds, s);
 }
 
+// out[b] = lad_scale * logabsdet[b] + sum_d (-z[b,d]^2 / 2 - log(2 pi) / 2): the N(0, I) base density joined with the
+// flow's log|det J| in one pass (reference: distributions.py:105-107 summed per sample, + the `+ logabsdet` of
+// distributions.py:154-157 / the `- logabsdet` of :173-186).  One wave per row, lanes stride the row in 16-byte
+// pieces when they can, fixed-order shuffle reduction: deterministic.
+__global__ __launch_bounds__(256) void std_normal_logp_kernel(const float* __restrict__ z, int64_t ldz, int64_t B, int D,
+                                                              const float* __restrict__ lad, float lad_scale,
+                                                              float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* p = z + row * ldz;
+    float s = 0.f;
+    if (D % 4 == 0 && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0) {
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(p + c);
+            s += (-0.5f * (v.x * v.x) - 0.918938533204672742f) + (-0.5f * (v.y * v.y) - 0.918938533204672742f);
+            s += (-0.5f * (v.z * v.z) - 0.918938533204672742f) + (-0.5f * (v.w * v.w) - 0.918938533204672742f);
+        }
+    } else {
+        for (int c = lane; c < D; c += 64) s += -0.5f * (p[c] * p[c]) - 0.918938533204672742f;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = lad ? lad_scale * lad[row] + s : s;
+}
+
+extern "C" int nf_std_normal_log_prob(const float* z, int64_t z_row_stride, const float* logabsdet, double lad_scale,
+                                      float* out, int64_t B, int D, void* stream) {
+    if (B < 0 || D <= 0) return NF_ERR_SHAPE;
+    if (B == 0) return NF_OK;
+    if (!z || !out) return NF_ERR_NULL;
+    if (z_row_stride < D) return NF_ERR_LAYOUT;
+    const int64_t grid = (B + 3) / 4;
+    if (grid > 0x7fffffff) return NF_ERR_SHAPE;
+    hipLaunchKernelGGL(std_normal_logp_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, z, z_row_stride, B,
+                       D, logabsdet, (float)lad_scale, out);
+    return nf_launch_status();
+}
+
 extern "C" int nf_affine_fwd(const float* x, int64_t x_row_stride, const int32_t* feat_index,
                              const float* params, int64_t param_row_stride, int layout,
                              float* y, int64_t y_row_stride, float* logabsdet, int accumulate,

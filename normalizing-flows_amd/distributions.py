@@ -71,10 +71,25 @@ class StandardNormal(Distribution):
         self.generator = None
 
     def _log_prob(self, inputs, context=None):
+        return self.log_prob_plus(inputs, None, 1.0)
+
+    def log_prob_plus(self, inputs, logabsdet, sign=1.0):
+        """log N(inputs; 0, I) + sign * logabsdet.  On the GPU, outside autograd, one launch (nf_std_normal_log_prob)
+        instead of the pow / mul / add / sum / add chain; under autograd the reference's ops (differentiable)."""
         if inputs.shape[1:] != self._shape:
             raise ValueError('Expected input of shape {}, got {}'.format(self._shape, inputs.shape[1:]))
         n = inputs.shape[0]
-        return (-0.5 * inputs.pow(2) - 0.5 * math.log(2 * math.pi)).reshape(n, -1).sum(dim=1)
+        recording = torch.is_grad_enabled() and (inputs.requires_grad or
+                                                 (logabsdet is not None and logabsdet.requires_grad))
+        if inputs.is_cuda and inputs.dtype == torch.float32 and not recording and n > 0 and \
+                (logabsdet is None or logabsdet.dtype == torch.float32):
+            from . import _lib
+            z = inputs.reshape(n, -1)
+            if z.stride(1) != 1:
+                z = z.contiguous()
+            return _lib.std_normal_log_prob(z, logabsdet, sign)
+        lp = (-0.5 * inputs.pow(2) - 0.5 * math.log(2 * math.pi)).reshape(n, -1).sum(dim=1)
+        return lp if logabsdet is None else lp + sign * logabsdet
 
     def _sample(self, num_samples, context=None):
         return torch.randn(num_samples, *self._shape, device=self._anchor.device, generator=self.generator)
@@ -94,6 +109,8 @@ class BaseNeuralSplineFlow(Distribution):
 
     def _log_prob(self, inputs, context):
         noise, logabsdet = self._transform(inputs, context=context)
+        if hasattr(self._distribution, 'log_prob_plus'):
+            return self._distribution.log_prob_plus(noise, logabsdet, 1.0)        # base density + logdet in one launch
         return self._distribution.log_prob(noise, context=context) + logabsdet
 
     def _sample(self, num_samples, context):
@@ -104,6 +121,10 @@ class BaseNeuralSplineFlow(Distribution):
         return samples
 
     def sample_and_log_prob(self, num_samples, context=None):
+        if hasattr(self._distribution, 'log_prob_plus') and context is None:
+            noise = self._distribution.sample(num_samples)
+            samples, logabsdet = self._transform.inverse(noise, context=None)
+            return samples, self._distribution.log_prob_plus(noise, logabsdet, -1.0)
         noise, log_prob = self._distribution.sample_and_log_prob(num_samples, context=context)
         samples, logabsdet = self._transform.inverse(noise, context=context)
         return samples, log_prob - logabsdet

@@ -828,6 +828,58 @@ def test_maf_legacy_fp64_golden(nf, D):
             assert rel_err(r.cpu(), fx['l%d/rev_z' % j]) < 1e-11 and rel_err(lj.cpu(), fx['l%d/rev_logJ' % j]) < 1e-11
 
 
+@pytest.mark.parametrize('B,D', [(1, 1), (7, 5), (300, 784), (129, 64)])
+def test_std_normal_log_prob_kernel(nf, B, D):
+    """nf_std_normal_log_prob: base density (distributions.py:105-107) + / - logabsdet in one launch, ragged widths,
+    strided rows, output aliasing the logdet."""
+    from normalizing_flows_amd import _lib
+    g = torch.Generator().manual_seed(B + D)
+    z = torch.randn(B, D + 3, generator=g) * 1.5
+    lad = torch.randn(B, generator=g) * 10
+    want = O.std_normal_log_prob(z[:, :D].double())
+    zd, ld = z.cuda(), lad.cuda()
+    assert rel_err(_lib.std_normal_log_prob(zd[:, :D]).cpu(), want) < 1e-6                       # strided rows
+    assert rel_err(_lib.std_normal_log_prob(zd[:, :D].contiguous(), ld, -1.0).cpu(), want - lad.double()) < 1e-6
+    dist_ = nf.StandardNormal([D]).cuda()
+    assert rel_err(dist_.log_prob(zd[:, :D]).cpu(), want) < 1e-6
+    zg = zd[:, :D].clone().requires_grad_(True)                                                    # autograd route
+    lp = dist_.log_prob(zg)
+    lp.sum().backward()
+    assert rel_err(lp.detach().cpu(), want) < 1e-6 and torch.allclose(zg.grad, -zd[:, :D], atol=1e-6)
+
+
+def test_sample_and_log_prob_against_the_oracle(nf):
+    """A18's sampling leg (distributions.py:173-186, model.py:78-85): x = T^-1(z), log q = base.log_prob(z) -
+    logabsdet_inv, against the oracle's D-pass inverse on the SAME noise (the flow's generator re-seeded)."""
+    fx = load_golden('rqar_small')
+    D, H, K, Tb = 16, 32, 8, 3.0
+    sd = golden_state_dict(fx)
+    layers = _load_layers(nf, [O.split_state_dict(sd, j) for j in range(3)], D, H, K, Tb)
+    flow = nf.BaseNeuralSplineFlow(nf.CompositeTransform(layers), nf.StandardNormal([D])).cuda().eval()
+    n = 200
+    gen = torch.Generator(device='cuda')
+    flow._distribution.generator = gen
+    gen.manual_seed(31)
+    with torch.no_grad():
+        xs, logq = flow.sample_and_log_prob(n)
+    gen.manual_seed(31)
+    z = torch.randn(n, D, device='cuda', generator=gen).cpu().double()
+    sds = [{k: (v.double() if v.is_floating_point() else v) for k, v in O.split_state_dict(sd, j).items()}
+           for j in range(3)]
+    x_ref, lad_ref = O.composite([lambda v, s=s: O.rq_autoregressive_inverse(s, v, K, Tb) for s in reversed(sds)], z)
+    want = O.std_normal_log_prob(z) - lad_ref
+    # the D-pass inverse is conditioning-limited (BASELINE.md 2): the bar is 4x the oracle's own fp32-vs-fp64 distance
+    sd32 = [O.split_state_dict(sd, j) for j in range(3)]
+    x32, lad32 = O.composite([lambda v, s=s: O.rq_autoregressive_inverse(s, v, K, Tb) for s in reversed(sd32)], z.float())
+    want32 = O.std_normal_log_prob(z.float()) - lad32
+    fx_, fl_ = rel_err(x32, x_ref), rel_err(want32, want)
+    ex, el = rel_err(xs.cpu(), x_ref), rel_err(logq.cpu(), want)
+    print('sample leg: x err %.2e (oracle fp32 floor %.2e), log q err %.2e (floor %.2e)' % (ex, fx_, el, fl_))
+    assert ex <= max(1e-5, 4 * fx_) and el <= max(1e-5, 4 * fl_)
+    with torch.no_grad():                                     # and log q of a sample is the density log_prob gives it
+        assert rel_err(flow.log_prob(xs).cpu(), want) <= max(1e-5, 4 * fl_)
+
+
 @pytest.mark.parametrize('mode', ['f32', 'f16x2'])
 def test_cfg4_streamed_log_likelihood_and_sampling(nf, mode):
     """BASELINE.json configs[3] on one GPU (world 1; the two-rank reduction runs under gloo in test_parallel.py):
