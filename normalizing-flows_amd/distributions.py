@@ -19,6 +19,28 @@ def _is_positive_int(x):
     return isinstance(x, int) and x > 0
 
 
+def split_leading_dim(x, shape):
+    """Reshapes the leading dim of x to `shape` (reference helper_functions.py:401-404)."""
+    return torch.reshape(x, torch.Size(shape) + x.shape[1:])
+
+
+def merge_leading_dims(x, num_dims):
+    """Merges the first num_dims dims of x into one (reference helper_functions.py:407-414)."""
+    if not _is_positive_int(num_dims):
+        raise TypeError('Number of leading dims must be a positive integer.')
+    if num_dims > x.dim():
+        raise ValueError('Number of leading dims can\'t be greater than total number of dims.')
+    return torch.reshape(x, torch.Size([-1]) + x.shape[num_dims:])
+
+
+def repeat_rows(x, num_reps):
+    """Each row of x repeated num_reps times along the leading dim (reference helper_functions.py:417-424)."""
+    if not _is_positive_int(num_reps):
+        raise TypeError('Number of repetitions must be a positive integer.')
+    shape = x.shape
+    return merge_leading_dims(x.unsqueeze(1).expand(shape[0], num_reps, *shape[1:]), num_dims=2)
+
+
 class Distribution(nn.Module):
     """Base class (reference distributions.py:7-69)."""
 
@@ -56,7 +78,17 @@ class Distribution(nn.Module):
 
     def sample_and_log_prob(self, num_samples, context=None):
         samples = self.sample(num_samples, context=context)
-        return samples, self.log_prob(samples, context=context)
+        if context is not None:
+            # merge the context dimension with the sample dimension to call log_prob, then split it off again
+            context = torch.as_tensor(context)
+            samples = merge_leading_dims(samples, num_dims=2)
+            context = repeat_rows(context, num_reps=num_samples)
+            assert samples.shape[0] == context.shape[0]
+        log_prob = self.log_prob(samples, context=context)
+        if context is not None:
+            samples = split_leading_dim(samples, shape=[-1, num_samples])
+            log_prob = split_leading_dim(log_prob, shape=[-1, num_samples])
+        return samples, log_prob
 
 
 class StandardNormal(Distribution):
@@ -92,7 +124,12 @@ class StandardNormal(Distribution):
         return lp if logabsdet is None else lp + sign * logabsdet
 
     def _sample(self, num_samples, context=None):
-        return torch.randn(num_samples, *self._shape, device=self._anchor.device, generator=self.generator)
+        if context is None:
+            return torch.randn(num_samples, *self._shape, device=self._anchor.device, generator=self.generator)
+        # one block of num_samples draws per context row: [context_size, num_samples, *shape]
+        context_size = context.shape[0]
+        return torch.randn(context_size * num_samples, *self._shape, device=self._anchor.device,
+                           generator=self.generator).reshape(context_size, num_samples, *self._shape)
 
     # legacy spelling used by models/model.py:78-108
     def sample_n(self, batch_size):
@@ -114,10 +151,14 @@ class BaseNeuralSplineFlow(Distribution):
         return self._distribution.log_prob(noise, context=context) + logabsdet
 
     def _sample(self, num_samples, context):
+        # reference distributions.py:159-171: with a context, num_samples draws per context row
+        noise = self._distribution.sample(num_samples, context=context)
         if context is not None:
-            raise NotImplementedError('conditional sampling is outside this path')
-        noise = self._distribution.sample(num_samples)
-        samples, _ = self._transform.inverse(noise, context=None)
+            noise = merge_leading_dims(noise, num_dims=2)
+            context = repeat_rows(context, num_reps=num_samples).contiguous()
+        samples, _ = self._transform.inverse(noise, context=context)
+        if context is not None:
+            samples = split_leading_dim(samples, shape=[-1, num_samples])
         return samples
 
     def sample_and_log_prob(self, num_samples, context=None):
@@ -125,8 +166,15 @@ class BaseNeuralSplineFlow(Distribution):
             noise = self._distribution.sample(num_samples)
             samples, logabsdet = self._transform.inverse(noise, context=None)
             return samples, self._distribution.log_prob_plus(noise, logabsdet, -1.0)
+        # reference distributions.py:173-186
         noise, log_prob = self._distribution.sample_and_log_prob(num_samples, context=context)
+        if context is not None:
+            noise = merge_leading_dims(noise, num_dims=2)
+            context = repeat_rows(torch.as_tensor(context), num_reps=num_samples).contiguous()
         samples, logabsdet = self._transform.inverse(noise, context=context)
+        if context is not None:
+            samples = split_leading_dim(samples, shape=[-1, num_samples])
+            logabsdet = split_leading_dim(logabsdet, shape=[-1, num_samples])
         return samples, log_prob - logabsdet
 
     def transform_to_noise(self, inputs, context=None):
