@@ -379,6 +379,16 @@ int nf_rqs_bwd(const float* x, int64_t x_row_stride, const float* params, int64_
                int tails, double tail_bound, double min_bin_width, double min_bin_height,
                double min_derivative, void* stream);
 
+/* Backward of nf_rqs_fwd(inverse = 1, feat_index = NULL) - the sampling direction the reference's default reverse-KL
+ * loss differentiates (model.py:135-139 through :78-85): x_out is that pass's OUTPUT (nothing else is saved), and by
+ * implicit differentiation of y_in = f(x_out; params) the kernel turns grad_x_out [B,D] and grad_logabsdet [B] into
+ * grad_y_in [B,D] (the spline's direct part) and grad_params [B, D*P]. */
+int nf_rqs_inverse_bwd(const float* x_out, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                       double pre_div, const float* grad_x_out, int64_t grad_x_out_row_stride,
+                       const float* grad_logabsdet, float* grad_y_in, int64_t grad_y_in_row_stride, float* grad_params,
+                       int64_t B, int D, int K, int tails, double tail_bound, double min_bin_width,
+                       double min_bin_height, double min_derivative, void* stream);
+
 /* ---- legacy Gaussian MAF layer, float64 (replaces models/flows.py:239-263 MaskedAutoregressiveFlow on
  *      models/made.py:11-89 SimpleMADE; the reference runs this class in float64 only) ---------------- */
 

@@ -142,6 +142,10 @@ _SIGNATURES = {
     'nf_rqs_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p, _c.c_int64,
                               _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
                               _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_void_p]),
+    'nf_rqs_inverse_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p,
+                                      _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int,
+                                      _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double,
+                                      _c.c_void_p]),
     'nf_diag_mfma_loop': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_diag_stream_copy': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     'nf_fold_f64': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
@@ -420,7 +424,9 @@ def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=Tru
 
 
 def rqs_bwd(x, params, grad_y, grad_lad, num_bins, tails, tail_bound, pre_div=1.0, min_bin_width=1e-3,
-            min_bin_height=1e-3, min_derivative=1e-3):
+            min_bin_height=1e-3, min_derivative=1e-3, inverse=False):
+    """(grad wrt the spline's input, grad_params).  inverse: backward of the inverse direction - `x` is then that
+    pass's OUTPUT and grad_y the gradient wrt it (nf_rqs_inverse_bwd)."""
     lib = load()
     for t, n in ((x, 'inputs'), (params, 'params'), (grad_y, 'grad_y'), (grad_lad, 'grad_logabsdet')):
         _dev(t, n)
@@ -433,10 +439,11 @@ def rqs_bwd(x, params, grad_y, grad_lad, num_bins, tails, tail_bound, pre_div=1.
     gparams = torch.empty_like(params)
     gl = grad_lad.contiguous()
     with torch.cuda.device(x.device):
-        _check(lib.nf_rqs_bwd(xp, xs, pp, ps, float(pre_div), gyp, gys, gl.data_ptr(), gxp, gxs, gparams.data_ptr(), B,
-                              D, int(num_bins), 1 if tails == 'linear' else 0, float(tail_bound),
-                              float(min_bin_width), float(min_bin_height), float(min_derivative), _stream()),
-               'nf_rqs_bwd')
+        fn = lib.nf_rqs_inverse_bwd if inverse else lib.nf_rqs_bwd
+        _check(fn(xp, xs, pp, ps, float(pre_div), gyp, gys, gl.data_ptr(), gxp, gxs, gparams.data_ptr(), B,
+                  D, int(num_bins), 1 if tails == 'linear' else 0, float(tail_bound),
+                  float(min_bin_width), float(min_bin_height), float(min_derivative), _stream()),
+               'nf_rqs_inverse_bwd' if inverse else 'nf_rqs_bwd')
     return gx, gparams
 
 

@@ -7,7 +7,8 @@ model.py:233-244).  Here every forward kernel has a hand-written backward kernel
   MaskedLinearFn : y = act_in(x) @ (W*mask)^T + b (+ residual)
                    backward: grad_x = (grad_y @ (W*mask)) gated by x > 0   (nf_masked_linear_bwd_input)
                              grad_W = mask * grad_y^T @ act_in(x), grad_b  (nf_masked_linear_bwd_weight)
-  RqsFn          : (y, logabsdet) = spline(x; params), forward direction
+  RqsFn          : (y, logabsdet) = spline(x; params), forward direction, or the inverse direction differentiated
+                   implicitly at its output (nf_rqs_inverse_bwd)
   AffineFn       : (y, logabsdet) = sigmoid-scale affine(x; params), either direction, AR or coupling layout
                    backward: recompute-from-inputs kernel nf_rqs_bwd -> grad_x, grad_params
 """
@@ -86,25 +87,26 @@ class MaskedLinearFn(torch.autograd.Function):
 
 class RqsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, params, num_bins, tails, tail_bound, mins, pre_div=1.0):
-        y, lad, _ = _lib.rqs(x, params, num_bins, tails, tail_bound, pre_div=pre_div, min_bin_width=mins[0],
-                             min_bin_height=mins[1], min_derivative=mins[2])
-        ctx.save_for_backward(x, params)
-        ctx.cfg = (num_bins, tails, tail_bound, mins, pre_div)
+    def forward(ctx, x, params, num_bins, tails, tail_bound, mins, pre_div=1.0, inverse=False):
+        y, lad, _ = _lib.rqs(x, params, num_bins, tails, tail_bound, inverse=inverse, pre_div=pre_div,
+                             min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2])
+        # the inverse direction is differentiated implicitly at its OUTPUT (nf_rqs_inverse_bwd): that is what it keeps
+        ctx.save_for_backward(y if inverse else x, params)
+        ctx.cfg = (num_bins, tails, tail_bound, mins, pre_div, inverse)
         return y, lad
 
     @staticmethod
     def backward(ctx, grad_y, grad_lad):
         x, params = ctx.saved_tensors
-        num_bins, tails, tail_bound, mins, pre_div = ctx.cfg
+        num_bins, tails, tail_bound, mins, pre_div, inverse = ctx.cfg
         if grad_y is None:
             grad_y = torch.zeros_like(x)
         if grad_lad is None:
             grad_lad = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
         gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
                                    pre_div=pre_div, min_bin_width=mins[0], min_bin_height=mins[1],
-                                   min_derivative=mins[2])
-        return gx, gparams, None, None, None, None, None
+                                   min_derivative=mins[2], inverse=inverse)
+        return gx, gparams, None, None, None, None, None, None
 
 
 class AffineFn(torch.autograd.Function):

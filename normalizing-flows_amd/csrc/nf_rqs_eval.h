@@ -323,8 +323,14 @@ __device__ __forceinline__ void rqs_inverse_pair(PT p, float x, const RqsConst& 
 // Recomputes the forward quantities from (x, params) instead of saving ~10 intermediates per element
 // (what autograd keeps for the reference's op sequence), then overwrites the element's P parameters in
 // `p` (LDS) with their gradients.  gy = dL/dy, gl = dL/d(logabsdet of this sample).  Returns dL/dx.
+// inv: backward of the INVERSE direction, x_out = f^-1(y_in), lad = -log f'(x_out).  Called at x = x_out (the inverse
+// pass's output) with gy = dL/dx_out and gl = dL/dlad; by implicit differentiation of y_in = f(x_out; params)
+//   dL/dy_in  = a = (gy - gl * d(log f')/dx) / f'(x)
+//   dL/dparams = -[ a * df/dparams + gl * d(log f')/dparams ]   = minus the forward-direction backward with (gy, gl) := (a, gl)
+// so the same formulas run on the substituted upstream gradient and the parameter gradients change sign.  Returns a.
 template <int KT>
-__device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, float gy, float gl, const RqsConst& a) {
+__device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, float gy, float gl, const RqsConst& a,
+                                              bool inv = false) {
     const int K = KT > 0 ? KT : a.K;
     const int P = a.P;
     if (a.tails && !(x >= a.left && x <= a.right)) {   // identity tail: y = x, ld = 0
@@ -395,6 +401,12 @@ __device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, fl
     const float M = d1 * t * t + 2.0f * s * q + d0 * omt * omt;
 
     const float rDn = nf_rcp(Dn), rbw = nf_rcp(bw);
+    if (inv) {
+        const float fp = (s * s) * M * (rDn * rDn);                                        // f'(x)
+        const float Mt = 2.0f * d1 * t + 2.0f * s * (1.0f - 2.0f * t) - 2.0f * d0 * omt;   // dM/dt
+        const float ldx = rbw * (nf_div(Mt, M) - 2.0f * c * (1.0f - 2.0f * t) * rDn);      // d(log f')/dx
+        gy = nf_div(gy - gl * ldx, fp);
+    }
     const float A = gy * rDn;                                  // dL/dN
     const float Bc = -gy * N * (rDn * rDn) - 2.0f * gl * rDn;  // dL/dDn
     const float Cm = nf_div(gl, M);                            // dL/dM
@@ -435,11 +447,11 @@ __device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, fl
         const float gh = a.scale_h * ((k < bin ? Gh0 : 0.0f) + (k <= bin ? Gh1 : 0.0f));
         float ow = (w * rw) * (gw - dotw), oh = (h * rh) * (gh - doth);
         if (scaled) { ow = nf_div(ow, a.pre_div); oh = nf_div(oh, a.pre_div); }
-        uw[k] = ow;
-        uh[k] = oh;
+        uw[k] = inv ? -ow : ow;
+        uh[k] = inv ? -oh : oh;
     }
     for (int j = 0; j < nd; ++j) ud[j] = 0.0f;
-    if (i0 >= 0) ud[i0] = g_d0 * sig0;
-    if (i1 >= 0) ud[i1] = g_d1 * sig1;
-    return gx;
+    if (i0 >= 0) ud[i0] = inv ? -(g_d0 * sig0) : g_d0 * sig0;
+    if (i1 >= 0) ud[i1] = inv ? -(g_d1 * sig1) : g_d1 * sig1;
+    return inv ? gy : gx;
 }

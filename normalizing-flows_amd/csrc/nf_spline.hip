@@ -151,6 +151,7 @@ struct RqsBwdArgs {
     RqsConst c;
     int rows_per_block;
     int vec_ok;                // params AND gparams 16-byte aligned
+    int inverse;               // backward of the inverse direction (x = the inverse pass's OUTPUT, see rqs_bwd_eval)
 };
 
 template <int KT, int MAXV>
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
             const float xv = a.x[(row0 + r) * a.x_stride + d];
             const float gyv = a.gy[(row0 + r) * a.gy_stride + d];
             const float gl = a.glad[row0 + r];
-            a.gx[(row0 + r) * a.gx_stride + d] = rqs_bwd_eval<KT>(stage + shift + tid * P, xv, gyv, gl, a.c);
+            a.gx[(row0 + r) * a.gx_stride + d] = rqs_bwd_eval<KT>(stage + shift + tid * P, xv, gyv, gl, a.c, a.inverse != 0);
         }
         __syncthreads();
         // write the gradients of this span back: whole 16-byte vectors inside the span, scalars at its ends
@@ -575,11 +576,11 @@ extern "C" int nf_affine_bwd(const float* x, int64_t x_row_stride, const int32_t
     return nf_launch_status();
 }
 
-extern "C" int nf_rqs_bwd(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
-                          double pre_div, const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
-                          float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D, int K,
-                          int tails, double tail_bound, double min_bin_width, double min_bin_height,
-                          double min_derivative, void* stream) {
+static int rqs_bwd_impl(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                        double pre_div, const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
+                        float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D, int K,
+                        int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                        double min_derivative, int inverse, void* stream) {
     if (B < 0 || D <= 0 || K <= 0 || K > 32) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
     if (B == 0) return NF_OK;
@@ -594,6 +595,7 @@ extern "C" int nf_rqs_bwd(const float* x, int64_t x_row_stride, const float* par
     a.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, pre_div);
     a.rows_per_block = pick_rows_per_block(D, B);
     a.vec_ok = (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0;
+    a.inverse = inverse;
     const size_t lds = sizeof(float) * (size_t)((kThreads * P + 4 + 3) & ~3);
     const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
@@ -605,4 +607,27 @@ extern "C" int nf_rqs_bwd(const float* x, int64_t x_row_stride, const float* par
         case 16: return launch_rqs_bwd_k<16>(a, (int)grid, lds, s);
         default: return launch_rqs_bwd_k<0>(a, (int)grid, lds, s);
     }
+}
+
+extern "C" int nf_rqs_bwd(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                          double pre_div, const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
+                          float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D, int K,
+                          int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                          double min_derivative, void* stream) {
+    return rqs_bwd_impl(x, x_row_stride, params, param_row_stride, pre_div, grad_y, grad_y_row_stride, grad_logabsdet,
+                        grad_x, grad_x_row_stride, grad_params, B, D, K, tails, tail_bound, min_bin_width,
+                        min_bin_height, min_derivative, 0, stream);
+}
+
+// Backward of nf_rqs_fwd(inverse = 1): x_out = the inverse pass's OUTPUT, grad_x_out / grad_logabsdet the gradients
+// wrt that output and its (negated) logdet; writes the gradient wrt the pass's INPUT and wrt the parameters.
+extern "C" int nf_rqs_inverse_bwd(const float* x_out, int64_t x_row_stride, const float* params,
+                                  int64_t param_row_stride, double pre_div, const float* grad_x_out,
+                                  int64_t grad_x_out_row_stride, const float* grad_logabsdet, float* grad_y_in,
+                                  int64_t grad_y_in_row_stride, float* grad_params, int64_t B, int D, int K, int tails,
+                                  double tail_bound, double min_bin_width, double min_bin_height,
+                                  double min_derivative, void* stream) {
+    return rqs_bwd_impl(x_out, x_row_stride, params, param_row_stride, pre_div, grad_x_out, grad_x_out_row_stride,
+                        grad_logabsdet, grad_y_in, grad_y_in_row_stride, grad_params, B, D, K, tails, tail_bound,
+                        min_bin_width, min_bin_height, min_derivative, 1, stream);
 }

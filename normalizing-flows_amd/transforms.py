@@ -107,10 +107,28 @@ class AutoregressiveTransform(nn.Module):
     def _forward_autograd(self, inputs, context):
         raise NotImplementedError('this transform has no backward kernels: call under torch.no_grad()')
 
+    def _inverse_autograd(self, inputs, context):
+        """The sampling direction under autograd (what the reference's default reverse-KL loss differentiates,
+        model.py:135-139 through :78-85): the reference's own D conditioner passes (transforms.py:493-500), every one of
+        them recorded - conditioner GEMMs as MaskedLinearFn, the elementwise inverse as this transform's
+        `_elementwise_autograd`.  Memory grows with D like the reference's; meant for the low-dimensional flows the
+        reference trains this way (its scripts use D = 2)."""
+        D = inputs.shape[1]
+        inputs = inputs.contiguous()
+        outputs = torch.zeros_like(inputs)
+        logabsdet = None
+        for _ in range(D):
+            params = self.autoregressive_net(outputs, context)
+            outputs, logabsdet = self._elementwise_autograd(inputs, params, inverse=True)
+        return outputs, logabsdet
+
+    def _elementwise_autograd(self, inputs, params, inverse):
+        raise NotImplementedError('this transform has no backward kernels: call under torch.no_grad()')
+
     def inverse(self, inputs, context=None):
         _check_2d(inputs, self.autoregressive_net.initial_layer.in_features)
         if self._recording(inputs):
-            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
+            return self._inverse_autograd(inputs, context)
         B, D = inputs.shape
         outputs = torch.zeros_like(inputs)
         logabsdet = torch.zeros(B, dtype=inputs.dtype, device=inputs.device)
@@ -133,7 +151,8 @@ class AutoregressiveTransform(nn.Module):
         behind gives every feature and logabsdet in one final-layer GEMM + one elementwise pass."""
         net = self.autoregressive_net
         if self._recording(inputs):
-            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
+            _check_2d(inputs, net.initial_layer.in_features)
+            return self._inverse_autograd(inputs, context)
         pi = net.inverse_rows_pack(num_bins, tails, kind=kind) if ROW_RESIDENT_INVERSE else None
         if pi is None:
             return AutoregressiveTransform.inverse(self, inputs, context)
@@ -185,10 +204,12 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
 
     def _forward_autograd(self, inputs, context):
         """Training path: conditioner (MaskedLinearFn) and the affine map (AffineFn) over the backward kernels."""
-        from .autograd import AffineFn
         x = inputs.contiguous()
-        params = self.autoregressive_net(x, context)
-        return AffineFn.apply(x, params, _lib.NF_AFFINE_INTERLEAVED, False, None, None)
+        return self._elementwise_autograd(x, self.autoregressive_net(x, context), inverse=False)
+
+    def _elementwise_autograd(self, inputs, params, inverse):
+        from .autograd import AffineFn
+        return AffineFn.apply(inputs, params.contiguous(), _lib.NF_AFFINE_INTERLEAVED, bool(inverse), None, None)
 
     def inverse(self, inputs, context=None):
         return self._inverse_via_rows(inputs, context, 'affine', None, None,
@@ -253,10 +274,13 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
     def _forward_autograd(self, inputs, context):
         """Training path: conditioner and spline as autograd.Functions over the backward kernels.  The
         parameter tensor is materialised here (the backward needs it); inference uses the fused kernel."""
-        from .autograd import RqsFn
         params = self.autoregressive_net(inputs.contiguous(), context)      # context: extra GEMM + GLU gates (torch glue)
-        return RqsFn.apply(inputs.contiguous(), params, self.num_bins, self.tails, self.tail_bound,
-                           (self.min_bin_width, self.min_bin_height, self.min_derivative))
+        return self._elementwise_autograd(inputs.contiguous(), params, inverse=False)
+
+    def _elementwise_autograd(self, inputs, params, inverse):
+        from .autograd import RqsFn
+        return RqsFn.apply(inputs, params.contiguous(), self.num_bins, self.tails, self.tail_bound,
+                           (self.min_bin_width, self.min_bin_height, self.min_derivative), 1.0, bool(inverse))
 
     def _feature_groups(self):
         """Consecutive features that can be inverted in the same pass.  Feature i (0-based, MADE degree
@@ -286,7 +310,8 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         fixed stay exactly zero in the network input, as in the reference's first pass."""
         net = self.autoregressive_net
         if self._recording(inputs):
-            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
+            _check_2d(inputs, net.initial_layer.in_features)
+            return self._inverse_autograd(inputs, context)
         if not self._fusable() or (context is not None and not (ROW_RESIDENT_INVERSE and net.inverse_rows_pack(self.num_bins, self.tails))):
             return super().inverse(inputs, context)
         D = net.initial_layer.in_features
@@ -461,9 +486,9 @@ class CouplingTransform(nn.Module):
         assert self.num_identity_features + self.num_transform_features == self.features
         self.transform_net = transform_net_create_fn(
             self.num_identity_features, self.num_transform_features * self._transform_dim_multiplier())
-        if unconditional_transform is not None:
-            raise NotImplementedError('unconditional transforms on the identity half are outside this path')
-        self.unconditional_transform = None
+        # optional transform of the identity half itself (reference transforms.py:65-70, :98-101, :120-123)
+        self.unconditional_transform = None if unconditional_transform is None else \
+            unconditional_transform(features=self.num_identity_features)
 
     @property
     def num_identity_features(self):
@@ -507,10 +532,24 @@ class CouplingTransform(nn.Module):
         return outputs, logabsdet
 
     def forward(self, inputs, context=None):
-        return self._run(inputs, context, inverse=False)
+        if self.unconditional_transform is None:
+            return self._run(inputs, context, inverse=False)
+        # the conditioner reads the ORIGINAL identity half; its own transform is applied to the output afterwards
+        outputs, logabsdet = self._run(inputs, context, inverse=False)
+        identity_split, logabsdet_identity = self.unconditional_transform(
+            inputs[:, self.identity_features].contiguous(), context)
+        return outputs.index_copy(1, self.identity_features, identity_split), logabsdet + logabsdet_identity
 
     def inverse(self, inputs, context=None):
-        return self._run(inputs, context, inverse=True)
+        if self.unconditional_transform is None:
+            return self._run(inputs, context, inverse=True)
+        # undo the identity half's own transform first: the conditioner must see what it saw in forward()
+        _check_2d(inputs, self.features)
+        identity_split, logabsdet_identity = self.unconditional_transform.inverse(
+            inputs[:, self.identity_features].contiguous(), context)
+        outputs, logabsdet = self._run(inputs.index_copy(1, self.identity_features, identity_split), context,
+                                       inverse=True)
+        return outputs, logabsdet_identity + logabsdet
 
     def _transform_dim_multiplier(self):
         raise NotImplementedError()
@@ -552,9 +591,14 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         self.min_derivative = min_derivative
         self.tails = tails
         self.tail_bound = tail_bound
-        if apply_unconditional_transform or img_shape:
-            raise NotImplementedError('unconditional / image transforms are outside this path')
-        super().__init__(mask, transform_net_create_fn, unconditional_transform=None)
+        if img_shape:
+            raise NotImplementedError('image (4-D) inputs are outside this path')
+        unconditional_transform = None
+        if apply_unconditional_transform:
+            unconditional_transform = lambda features: PiecewiseRationalQuadraticCDF(       # noqa: E731
+                shape=[features], num_bins=num_bins, tails=tails, tail_bound=tail_bound, min_bin_width=min_bin_width,
+                min_bin_height=min_bin_height, min_derivative=min_derivative)
+        super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
 
     def _transform_dim_multiplier(self):
         if self.tails == 'linear':
@@ -601,12 +645,10 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         return outputs, logabsdet
 
     def _run_autograd(self, inputs, context, inverse):
-        """Training path, forward direction: the transformed columns are gathered (torch ops, differentiable), the
-        spline and its backward run as RqsFn (nf_rqs_fwd / nf_rqs_bwd with the coupling pre-divisor), and the result
-        is scattered back beside the identity columns."""
+        """Training path, either direction: the transformed columns are gathered (torch ops, differentiable), the
+        spline and its backward run as RqsFn (nf_rqs_fwd / nf_rqs_bwd / nf_rqs_inverse_bwd with the coupling
+        pre-divisor), and the result is scattered back beside the identity columns."""
         from .autograd import RqsFn
-        if inverse:
-            raise NotImplementedError('the inverse direction has no backward kernels: call under torch.no_grad()')
         if self.tails not in (None, 'linear'):
             raise RuntimeError('{} tails are not implemented.'.format(self.tails))
         identity_split = inputs[:, self.identity_features].contiguous()
@@ -614,7 +656,7 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         xt = inputs.index_select(1, self.transform_features).contiguous()
         yt, logabsdet = RqsFn.apply(xt, params, self.num_bins, self.tails, self.tail_bound,
                                     (self.min_bin_width, self.min_bin_height, self.min_derivative),
-                                    float(self._pre_div()))
+                                    float(self._pre_div()), bool(inverse))
         return inputs.index_copy(1, self.transform_features, yt), logabsdet
 
     def _coupling_elementwise(self, inputs, transform_params, outputs, logabsdet, inverse):
@@ -625,6 +667,58 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
                  pre_div=pre_div, feat_index=self._feat_index(), out=outputs, logabsdet=logabsdet,
                  min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                  min_derivative=self.min_derivative, num_features=self.num_transform_features)
+
+
+class PiecewiseRationalQuadraticCDF(nn.Module):
+    """Elementwise RQ spline with LEARNED, batch-independent parameters (reference transforms.py:249-318): what
+    `apply_unconditional_transform=True` puts on a coupling layer's identity half.  `shape` = [features] (2-D inputs).
+    Runs on the spline kernel (nf_rqs_fwd / nf_rqs_bwd) with the parameter row shared across the batch."""
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1., identity_init=False,
+                 min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
+                 min_derivative=DEFAULT_MIN_DERIVATIVE):
+        super().__init__()
+        shape = list(shape)
+        if len(shape) != 1:
+            raise NotImplementedError('image (4-D) inputs are outside this path')
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tail_bound = tail_bound
+        self.tails = tails
+        num_derivatives = (num_bins - 1) if tails == 'linear' else (num_bins + 1)
+        if identity_init:
+            self.unnormalized_widths = nn.Parameter(torch.zeros(*shape, num_bins))
+            self.unnormalized_heights = nn.Parameter(torch.zeros(*shape, num_bins))
+            constant = np.log(np.exp(1 - min_derivative) - 1)
+            self.unnormalized_derivatives = nn.Parameter(constant * torch.ones(*shape, num_derivatives))
+        else:
+            self.unnormalized_widths = nn.Parameter(torch.rand(*shape, num_bins))
+            self.unnormalized_heights = nn.Parameter(torch.rand(*shape, num_bins))
+            self.unnormalized_derivatives = nn.Parameter(torch.rand(*shape, num_derivatives))
+
+    def _spline(self, inputs, inverse=False):
+        if self.tails not in (None, 'linear'):
+            raise RuntimeError('{} tails are not implemented.'.format(self.tails))
+        _check_2d(inputs, self.unnormalized_widths.shape[0])
+        B = inputs.shape[0]
+        inputs = inputs.contiguous()
+        row = torch.cat([self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives], dim=-1)
+        params = row.reshape(1, -1).expand(B, -1).contiguous()       # the kernel reads one parameter row per sample
+        mins = (self.min_bin_width, self.min_bin_height, self.min_derivative)
+        if torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad):
+            from .autograd import RqsFn
+            return RqsFn.apply(inputs, params, self.num_bins, self.tails, self.tail_bound, mins, 1.0, bool(inverse))
+        y, lad, _ = _lib.rqs(inputs, params, self.num_bins, self.tails, self.tail_bound, inverse=inverse,
+                             min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2])
+        return y, lad
+
+    def forward(self, inputs, context=None):
+        return self._spline(inputs, inverse=False)
+
+    def inverse(self, inputs, context=None):
+        return self._spline(inputs, inverse=True)
 
 
 class PiecewiseCubicCouplingTransform(CouplingTransform):

@@ -21,6 +21,7 @@ Reference lines followed (all under /root/reference):
   simple_made_forward ............................. models/made.py:11-89
   rq_autoregressive / affine_autoregressive ....... models/transforms.py:488-500, 540-566, 819-860
   coupling (rq / affine) .......................... models/transforms.py:80-135, 156-168, 212-247, 328-347
+  rq_cdf (unconditional transform) ................ models/transforms.py:249-318
   residual_net_forward ............................ models/nn/resnet.py:38-57, 90-100
   maf_forward / maf_reverse ....................... models/flows.py:239-263
   legacy_flow_to_samples / legacy_reverse_to_samples models/model.py:87-108
@@ -333,13 +334,37 @@ def residual_net_forward(sd, x, prefix='transform_net.', context=None):
     return F.linear(h, sd[p + 'final_layer.weight'], sd[p + 'final_layer.bias'])
 
 
-def _coupling(sd, x, elementwise):
-    """Split by index buffers, conditioner on identity half, scatter.  transforms.py:80-135."""
+def rq_cdf(sd, x, tails, tail_bound, inverse=False, mins=(1e-3, 1e-3, 1e-3), prefix='unconditional_transform.'):
+    """PiecewiseRationalQuadraticCDF: learned parameters shared across the batch.  transforms.py:284-318."""
+    b = x.shape[0]
+    uw = sd[prefix + 'unnormalized_widths'][None, ...].expand(b, -1, -1)
+    uh = sd[prefix + 'unnormalized_heights'][None, ...].expand(b, -1, -1)
+    ud = sd[prefix + 'unnormalized_derivatives'][None, ...].expand(b, -1, -1)
+    if tails is None:
+        y, ld = rq_spline(x, uw, uh, ud, inverse=inverse, min_bin_width=mins[0], min_bin_height=mins[1],
+                          min_derivative=mins[2])
+    else:
+        y, ld = rq_spline_linear_tails(x, uw, uh, ud, inverse=inverse, tail_bound=tail_bound, min_bin_width=mins[0],
+                                       min_bin_height=mins[1], min_derivative=mins[2])
+    return y, sum_except_batch(ld)
+
+
+def _coupling(sd, x, elementwise, unconditional=None, inverse=False):
+    """Split by index buffers, conditioner on identity half, scatter.  transforms.py:80-135.
+    unconditional(ident, inverse) -> (ident', logabsdet): the identity half's own transform (:98-101 after the
+    conditioner has read the original half in forward; :120-123 before the conditioner in inverse)."""
     idf = sd['identity_features']
     trf = sd['transform_features']
     ident = x[:, idf]
+    lad_id = None
+    if unconditional is not None and inverse:
+        ident, lad_id = unconditional(ident, True)
     params = residual_net_forward(sd, ident)
     t, lad = elementwise(x[:, trf], params)
+    if unconditional is not None and not inverse:
+        ident, lad_id = unconditional(ident, False)
+    if lad_id is not None:
+        lad = lad + lad_id
     out = torch.empty_like(x)
     out[:, idf] = ident
     out[:, trf] = t
@@ -347,7 +372,7 @@ def _coupling(sd, x, elementwise):
 
 
 def rq_coupling(sd, x, num_bins, tails, tail_bound, hidden_features, inverse=False,
-                mins=(1e-3, 1e-3, 1e-3), return_bins=False):
+                mins=(1e-3, 1e-3, 1e-3), return_bins=False, unconditional=False):
     """RQ coupling layer, ResidualNet conditioner.  transforms.py:156-168, 212-247.
     widths/heights are divided by sqrt(hidden_features) (ResidualNet sets the attribute)."""
     bins_box = []
@@ -372,7 +397,8 @@ def rq_coupling(sd, x, num_bins, tails, tail_bound, hidden_features, inverse=Fal
             bins_box.append(res[2])
         return res[0], sum_except_batch(res[1])
 
-    out, lad = _coupling(sd, x, elementwise)
+    unc = (lambda v, inv: rq_cdf(sd, v, tails, tail_bound, inverse=inv, mins=mins)) if unconditional else None
+    out, lad = _coupling(sd, x, elementwise, unconditional=unc, inverse=inverse)
     if return_bins:
         return out, lad, bins_box[0]
     return out, lad

@@ -337,6 +337,40 @@ def gen_affine_coupling():
          features=D, n_layers=3, **sd_np(comp.state_dict(), 'sd/'))
 
 
+def gen_unconditional_coupling():
+    """RQ coupling layers with apply_unconditional_transform=True (transforms.py:196-206: a PiecewiseRationalQuadraticCDF,
+    :249-318, on the identity half), odd feature count so the halves differ; forward and inverse."""
+    D, K, T, Hn, L = 9, 6, 3.0, 32, 3
+    for tails, tag in [('linear', 'linear'), (None, 'notails')]:
+        torch.manual_seed(45)
+        layers = []
+        for j in range(L):
+            mask = helper_functions.create_alternating_binary_mask(D, even=(j % 2 == 0))
+            layers.append(transforms.PiecewiseRationalQuadraticCouplingTransform(
+                mask=mask,
+                transform_net_create_fn=lambda i, o: resnet.ResidualNet(i, o, hidden_features=Hn, num_blocks=2),
+                num_bins=K, tails=tails, tail_bound=T, apply_unconditional_transform=True))
+        if tails is None:
+            comp = transforms.CompositeTransform(layers[:1]).eval()
+            x = torch.rand(128, D) * 0.98 + 0.01
+        else:
+            comp = transforms.CompositeTransform(layers).eval()
+            x = torch.randn(128, D) * 1.5
+        with torch.no_grad():
+            for n_, p in comp.named_parameters():
+                if 'unconditional' not in n_:
+                    p.mul_(1.5)
+            y, ld = comp(x)
+            xi, ldi = comp.inverse(y)
+            with f64():
+                y64, ld64 = comp.double()(x.double())
+                xi64, ldi64 = comp.inverse(y64)
+            comp.float()
+        save('rq_coupling_uncond_' + tag, x=x, y=y, ld=ld, inv_of_y=xi, inv_of_y_ld=ldi, y64=y64, ld64=ld64,
+             inv_of_y64=xi64, inv_of_y64_ld=ldi64, num_bins=K, tail_bound=T, hidden=Hn, features=D,
+             n_layers=len(comp._transforms), **sd_np(comp.state_dict(), 'sd/'))
+
+
 # ======================================================================= F5: legacy MAF (fp64)
 def gen_maf():
     torch.set_default_dtype(torch.float64)            # what main.py:21-24 selects on CPU
@@ -457,9 +491,13 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'maf_training':
         gen_maf_training()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'unconditional':
+        gen_unconditional_coupling()
+        sys.exit(0)
     gen_spline()
     gen_made()
     gen_rq_ar()
     gen_affine_coupling()
     gen_maf()
     gen_maf_training()
+    gen_unconditional_coupling()

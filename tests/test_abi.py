@@ -97,6 +97,19 @@ def test_transform_state_dict_surface():
     assert comp._transforms[0].transform_net.hidden_features == 32
     assert torch.equal(comp._transforms[1].transform_features, ref['_transforms.1.transform_features'])
 
+    # apply_unconditional_transform=True: the identity half's PiecewiseRationalQuadraticCDF and its three parameters
+    ref = golden_state_dict(load_golden('rq_coupling_uncond_linear'))
+    layers = []
+    for j in range(3):
+        mask = torch.zeros(9)
+        mask[(0 if j % 2 == 0 else 1)::2] = 1
+        layers.append(nf.PiecewiseRationalQuadraticCouplingTransform(
+            mask, lambda i, o: nf.ResidualNet(i, o, hidden_features=32, num_blocks=2), num_bins=6, tails='linear',
+            tail_bound=3.0, apply_unconditional_transform=True))
+    comp = nf.CompositeTransform(layers)
+    assert list(comp.state_dict().keys()) == list(ref.keys())
+    comp.load_state_dict(ref, strict=True)
+
 
 def test_constructor_errors_match_reference():
     with pytest.raises(ValueError):

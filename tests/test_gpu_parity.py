@@ -678,7 +678,7 @@ def test_affine_ar_golden(nf):
     assert rel_err(xs.cpu(), fx['xs']) < 10 * TOL and rel_err(lds.cpu(), fx['lds']) < TOL
 
 
-def _coupling_stack(nf, fx, kind):
+def _coupling_stack(nf, fx, kind, unconditional=False):
     D, Hn, L = int(fx['features']), int(fx['hidden']), int(fx['n_layers'])
     layers = []
     for j in range(L):
@@ -689,7 +689,8 @@ def _coupling_stack(nf, fx, kind):
             layers.append(nf.AffineCouplingTransform(mask, net_fn))
         else:
             layers.append(nf.PiecewiseRationalQuadraticCouplingTransform(
-                mask, net_fn, num_bins=int(fx['num_bins']), tails=kind, tail_bound=float(fx['tail_bound'])))
+                mask, net_fn, num_bins=int(fx['num_bins']), tails=kind, tail_bound=float(fx['tail_bound']),
+                apply_unconditional_transform=unconditional))
     comp = nf.CompositeTransform(layers)
     comp.load_state_dict(golden_state_dict(fx), strict=True)
     return comp.cuda().eval()
@@ -789,8 +790,11 @@ def test_module_errors(nf):
     with torch.no_grad():
         with pytest.raises(ValueError):                      # reference transforms.py:84-86 wording
             t(torch.zeros(3, 7, device='cuda'))
-    with pytest.raises(NotImplementedError):                 # no silent autograd fallback for the inverse
-        t.inverse(torch.zeros(3, 6, device='cuda'))
+    x, lad = t.inverse(torch.zeros(3, 6, device='cuda'))     # the inverse records too (implicit spline backward)
+    assert x.grad_fn is not None and lad.grad_fn is not None
+    tq = nf.MaskedPiecewiseQuadraticAutoregressiveTransform(6, 16, num_bins=4).cuda()
+    with pytest.raises(NotImplementedError):                 # families without backward kernels refuse to record
+        tq(torch.rand(3, 6, device='cuda'))
     with pytest.raises(ValueError):
         nf.MADE(4, 8, random_mask=True)                      # made.py:305-306
 
@@ -1495,6 +1499,93 @@ def test_rq_coupling_training_gradients(nf, tag):
     checked = 0
     for k, v in sd64.items():
         if k.endswith(('weight', 'bias')) and v.grad is not None:
+            got = named[k].grad.cpu().double()
+            assert (got - v.grad).abs().max().item() / (v.grad.abs().max().item() + 1e-12) < 2e-3, k
+            checked += 1
+    assert checked >= 6 * L
+
+
+@pytest.mark.parametrize('tag', ['linear', 'notails'])
+def test_rq_coupling_with_unconditional_transform_golden(nf, tag):
+    """apply_unconditional_transform=True (reference transforms.py:196-206: a PiecewiseRationalQuadraticCDF on the
+    identity half, applied after the conditioner has read it in forward and undone before it in inverse; odd feature
+    count, so the halves differ in size): forward / inverse against the reference's float64 results."""
+    fx = load_golden('rq_coupling_uncond_' + tag)
+    comp = _coupling_stack(nf, fx, 'linear' if tag == 'linear' else None, unconditional=True)
+    with torch.no_grad():
+        y, ld = comp(dev(fx['x']))
+        xi, ldi = comp.inverse(dev(fx['y']))
+    assert_close(y, fx['y64'], fx['y'])
+    assert_close(ld, fx['ld64'], fx['ld'])
+    assert rel_err(xi.cpu(), fx['x']) < 10 * TOL
+    assert_close(ldi, -fx['ld64'], fx['inv_of_y_ld'])
+
+
+@pytest.mark.parametrize('case', ['rq_coupling', 'rq_coupling_uncond', 'affine_coupling', 'rq_ar', 'affine_ar',
+                                  'rq_ar_context'])
+def test_inverse_direction_training_gradients(nf, case):
+    """The SAMPLING direction under autograd - what the reference's default reverse-KL loss differentiates
+    (model.py:135-139 through :78-85): x = T^-1(z), loss(x, logabsdet_inv).  Gradients wrt z and every parameter
+    against torch autograd through the oracle's inverse (for the autoregressive transforms: its D-pass loop) in
+    float64.  Spline inverses are differentiated implicitly at their output (nf_rqs_inverse_bwd)."""
+    g = torch.Generator().manual_seed(12)
+    if case in ('rq_coupling', 'rq_coupling_uncond', 'affine_coupling'):
+        unc = case == 'rq_coupling_uncond'
+        fx = load_golden({'rq_coupling': 'rq_coupling_linear', 'rq_coupling_uncond': 'rq_coupling_uncond_linear',
+                          'affine_coupling': 'affine_coupling'}[case])
+        kind = 'affine' if case == 'affine_coupling' else 'linear'
+        comp = _coupling_stack(nf, fx, kind, unconditional=unc)
+        sd = golden_state_dict(fx)
+        L, D = int(fx['n_layers']), int(fx['features'])
+        if kind == 'affine':
+            inv = lambda s_, v: O.affine_coupling(s_, v, inverse=True)
+        else:
+            K, Tb, Hn = int(fx['num_bins']), float(fx['tail_bound']), int(fx['hidden'])
+            inv = lambda s_, v: O.rq_coupling(s_, v, K, 'linear', Tb, Hn, inverse=True, unconditional=unc)
+        context = None
+    else:
+        D, H, K, Tb, L = 5, 16, 4, 3.0, 2
+        C = 3 if case == 'rq_ar_context' else None
+        torch.manual_seed(21)
+        if case == 'affine_ar':
+            layers = [nf.MaskedAffineAutoregressiveTransform(D, H) for _ in range(L)]
+            inv = lambda s_, v: O.affine_autoregressive_inverse(s_, v)
+        else:
+            layers = [nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(D, H, context_features=C, num_bins=K,
+                                                                                 tails='linear', tail_bound=Tb)
+                      for _ in range(L)]
+            inv = lambda s_, v: O.rq_autoregressive_inverse(s_, v, K, Tb, context=ctx64)
+        with torch.no_grad():
+            for t in layers:
+                for p in t.parameters():
+                    p.mul_(1.4 if C else 2.0)
+        comp = nf.CompositeTransform(layers)
+        sd = {k: v.detach().clone() for k, v in comp.state_dict().items()}
+        comp = comp.cuda()
+        context = torch.randn(40, C, generator=g) if C else None
+    ctx64 = None if context is None else context.double()
+    z = torch.randn(40, D, generator=g) * 1.2
+    zg = z.cuda().requires_grad_(True)
+    x, lad = comp.inverse(zg) if context is None else comp.inverse(zg, context.cuda())
+    assert x.grad_fn is not None and lad.grad_fn is not None
+    (x.square().sum() * 0.05 + (x * 0.3).sum() + lad.sum()).backward()
+    sd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() and not k.endswith(('mask', 'running_mean', 'running_var'))
+                else (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+    z64 = z.double().requires_grad_(True)
+    h, tot = z64, 0.
+    for j in reversed(range(L)):
+        h, l = inv(O.split_state_dict(sd64, j), h)
+        tot = tot + l
+    (h.square().sum() * 0.05 + (h * 0.3).sum() + tot.sum()).backward()
+    ev, el = rel_err(x.detach().cpu(), h.detach()), rel_err(lad.detach().cpu(), tot.detach())
+    assert ev < 1e-4 and el < 2e-3, (ev, el)       # (fp32 against the float64 oracle on doubled weights: conditioning)
+    gz = _nerr(zg.grad.cpu(), z64.grad)
+    print('inverse-direction gradient wrt z: normalised error %.2e, value errors %.1e / %.1e' % (gz, ev, el))
+    assert gz < 2e-3, gz
+    named = dict(comp.named_parameters())
+    checked = 0
+    for k, v in sd64.items():
+        if k in named and v.grad is not None:
             got = named[k].grad.cpu().double()
             assert (got - v.grad).abs().max().item() / (v.grad.abs().max().item() + 1e-12) < 2e-3, k
             checked += 1

@@ -169,6 +169,28 @@ def test_rq_coupling(tag):
     assert torch.equal(xi, T(fx['inv_of_y'])) and torch.equal(ldi, T(fx['inv_of_y_ld']))
 
 
+@pytest.mark.parametrize('tag', ['linear', 'notails'])
+def test_rq_coupling_with_unconditional_transform(tag):
+    """apply_unconditional_transform=True: a PiecewiseRationalQuadraticCDF on the identity half (transforms.py:98-101,
+    :120-123, :249-318), fixtures from the reference's classes."""
+    fx = load_golden('rq_coupling_uncond_' + tag)
+    sd = golden_state_dict(fx)
+    K, Tb, Hn, L = int(fx['num_bins']), float(fx['tail_bound']), int(fx['hidden']), int(fx['n_layers'])
+    tails = 'linear' if tag == 'linear' else None
+    layers = [O.split_state_dict(sd, j) for j in range(L)]
+    assert 'unconditional_transform.unnormalized_widths' in layers[0]
+    y, ld = O.composite([lambda v, s=s: O.rq_coupling(s, v, K, tails, Tb, Hn, unconditional=True) for s in layers],
+                        T(fx['x']))
+    assert torch.equal(y, T(fx['y'])) and torch.equal(ld, T(fx['ld']))
+    xi, ldi = O.composite([lambda v, s=s: O.rq_coupling(s, v, K, tails, Tb, Hn, inverse=True, unconditional=True)
+                           for s in reversed(layers)], y)
+    assert torch.equal(xi, T(fx['inv_of_y'])) and torch.equal(ldi, T(fx['inv_of_y_ld']))
+    l64 = [{k: (v.double() if v.is_floating_point() else v) for k, v in s_.items()} for s_ in layers]
+    y64, ld64 = O.composite([lambda v, s=s: O.rq_coupling(s, v, K, tails, Tb, Hn, unconditional=True) for s in l64],
+                            T(fx['x']).double())
+    assert torch.equal(y64, T(fx['y64'])) and torch.equal(ld64, T(fx['ld64']))
+
+
 def test_affine_coupling():
     fx = load_golden('affine_coupling')
     sd = golden_state_dict(fx)
