@@ -69,6 +69,23 @@ def check_bins(bins_hip, bins_ref, x, knots, tol):
     return n
 
 
+def compare_bins(name, bins_hip, b32, b64, allowed=0):
+    """Bin indices against the reference's searches: wherever its own fp32 and fp64 runs agree the HIP index must be
+    that index, up to `allowed` ADJACENT flips (elements a few ulp from a knot, where the last bit of the knot
+    decides); the count is printed, never averaged away."""
+    got = bins_hip.cpu().reshape(-1).long()
+    b32, b64 = torch.as_tensor(b32).reshape(-1).long(), torch.as_tensor(b64).reshape(-1).long()
+    agree = b32 == b64
+    mis = agree & (got != b64)
+    n = int(mis.sum())
+    print('%s: %d elements, reference fp32/fp64 disagree on %d, HIP differs from both on %d'
+          % (name, got.numel(), int((~agree).sum()), n))
+    if n:
+        assert ((got - b64).abs()[mis] == 1).all(), 'bin index off by more than one'
+    assert n <= allowed, (name, n)
+    return n
+
+
 # ------------------------------------------------------------------------------- spline alone
 @pytest.mark.parametrize('tag', ['K4_T1', 'K8_T3', 'K32_T50'])
 @pytest.mark.parametrize('direction', ['fwd', 'inv'])
@@ -273,6 +290,53 @@ def test_rq_ar_cfg3_golden(nf):
     floor = max(rel_err(fx['xs1'], fx['xs1_64']), TOL)
     assert rel_err(xs1.cpu(), fx['xs1_64']) < 4 * floor
     assert rel_err(lds1.cpu(), fx['lds1_64']) < TOL * 10
+
+
+@pytest.mark.parametrize('mode', ['f32', 'f16x2'])
+def test_bin_index_census_at_scale(nf, mode):
+    """one cfg-3 layer (D=784, H=512, K=8) on 262144 samples = 2.06e8 spline elements with the bin
+    index of every element written out.  (1) On every 128th row the indices are compared with the oracle's search
+    (fp32 ATen ops): a differing index must be the ADJACENT bin and the element must sit within 3e-6 (12 ulp of the
+    bound 3) of the knot between the two - where the spline is C1, so outputs still agree; the count is reported.
+    (2) Over ALL 2.06e8 elements the exact-fp32 and the f16x2 launches are compared with each other: differing
+    indices must be adjacent, and their count is reported."""
+    fx = load_golden('rqar_cfg3')
+    K, Tb, D, H = int(fx['num_bins']), float(fx['tail_bound']), int(fx['features']), int(fx['hidden'])
+    sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=int(fx['seeds'][0]))
+    layer = _load_layers(nf, [sd], D, H, K, Tb)[0].cuda().eval()
+    B = 262144
+    x = torch.randn(B, D, device='cuda', generator=torch.Generator(device='cuda').manual_seed(17))
+    nf.set_matmul_dtype(mode)
+    try:
+        with torch.no_grad():
+            bins = torch.cat([layer.forward_with_bins(x[s:s + 131072])[2] for s in range(0, B, 131072)])
+    finally:
+        nf.set_matmul_dtype('f32')
+    rows = torch.arange(0, B, 128, device='cuda')
+    xs = x[rows].cpu()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        params = O.made_forward(sd, xs, 'autoregressive_net.')
+        _, _, ref_bins = O._rq_ar_elementwise(xs, params, K, Tb, False, (1e-3, 1e-3, 1e-3), return_bins=True)
+        cum, _ = O._knots(params.view(-1, D, 3 * K - 1)[..., :K].double(), 1e-3, -Tb, Tb)
+    inside = (xs >= -Tb) & (xs <= Tb)
+    got = bins[rows].cpu().long()
+    assert (got[~inside] == -1).all()
+    ref_full = ref_bins.long()                                   # [rows, D], -1 in the tails
+    assert (ref_full[~inside] == -1).all()
+    flips = check_bins(got[inside], ref_full[inside], xs[inside], cum[inside], tol=3e-6)
+    n_el = int(inside.sum())
+    print('bin census [%s]: %d of %d sampled in-range elements (every 128th of 262144 rows) differ from the oracle, all '
+          'adjacent and within 3e-6 of the knot' % (mode, flips, n_el))
+    assert flips <= max(3, n_el // 100000)                       # measured: 0 of 1.6 M in both modes
+    if mode == 'f16x2':
+        with torch.no_grad():
+            other = torch.cat([layer.forward_with_bins(x[s:s + 131072])[2] for s in range(0, B, 131072)])
+        diff = other != bins
+        n = int(diff.sum())
+        assert n == 0 or ((other.long() - bins.long()).abs()[diff] == 1).all()
+        print('bin census: exact-fp32 vs f16x2 launches differ on %d of %d elements, all adjacent' % (n, bins.numel()))
+        assert n <= bins.numel() // 100000                       # measured: 42 of 2.06e8
 
 
 def test_rq_ar_roundtrip_and_chunking(nf):
@@ -1706,7 +1770,11 @@ def test_linear_spline_golden(nf, tag, direction):
                                         inverse=direction == 'inv', want_bins=True)
     assert_close(y.reshape(-1), fx[direction + '_y64'], fx[direction + '_y32'])
     assert_close(ld, fx[direction + '_ld64'], fx[direction + '_ld32'])
-    assert int(bins.max()) <= K - 1
+    # bin indices against the oracle's search (pinned to this fixture's values bit for bit in test_oracle.py)
+    xc, pc = T(fx[direction + '_x']), T(fx['params'])
+    fn = (lambda a, b: O.unconstrained_linear_spline(a, b, inverse=direction == 'inv', tail_bound=Tb, return_bins=True)) \
+        if tails else (lambda a, b: O.linear_spline(a, b, inverse=direction == 'inv', return_bins=True))
+    compare_bins('linear spline %s %s' % (tag, direction), bins, fn(xc, pc)[2], fn(xc.double(), pc.double())[2])
 
 
 @pytest.mark.parametrize('tag', ['K8_T3', 'K6_unit', 'K16_T10'])
@@ -1723,9 +1791,7 @@ def test_quadratic_spline_golden(nf, tag, direction):
     assert_close(y.reshape(-1), fx[direction + '_y64'], fx[direction + '_y32'], mult=16.0)
     assert_close(ld, fx[direction + '_ld64'], fx[direction + '_ld32'], mult=16.0)
     # bin indices: bit-exact wherever the reference's own fp32 and fp64 searches agree
-    b32, b64 = T(fx[direction + '_bins32']).long(), T(fx[direction + '_bins64']).long()
-    agree = b32 == b64
-    assert (bins.cpu().reshape(-1).long()[agree] == b64[agree]).float().mean().item() > 0.999
+    compare_bins('quadratic spline %s %s' % (tag, direction), bins, fx[direction + '_bins32'], fx[direction + '_bins64'])     # (measured on MI355X: 0 on every fixture)
     with pytest.raises(ValueError):                    # the reference's error (quadratic.py:64-67)
         nf._lib.quadratic_spline(x, dev(fx['params']), K, tails=tails, min_bin_width=0.5)
 
@@ -1799,8 +1865,7 @@ def test_cubic_spline_golden(nf, tag, direction):
                                        want_bins=True)
     _assert_close_noisy(y.reshape(-1), fx[direction + '_y64'], fx[direction + '_y32'])
     _assert_close_noisy(ld, fx[direction + '_ld64'], fx[direction + '_ld32'])
-    b64 = T(fx[direction + '_bins64']).long()
-    assert (bins.cpu().reshape(-1).long() == b64).float().mean().item() > 0.999
+    compare_bins('cubic spline %s %s' % (tag, direction), bins, fx[direction + '_bins32'], fx[direction + '_bins64'])     # (measured on MI355X: 0 on every fixture)
 
 
 def test_cubic_transforms_against_the_oracle(nf):
