@@ -7,7 +7,8 @@ submodule / buffer names (so a reference ``state_dict`` loads with ``strict=True
 tiles (nf_made_pack) and every layer runs as one fused MFMA kernel (nf_masked_linear_fwd) with the
 ReLU / eval-BatchNorm prologue and the bias / skip epilogue inside it.
 
-Scope of this build: ReLU activation (the reference default).  Inference (``eval()`` / no-grad) runs entirely on
+Activations: ReLU (the reference default) is fused into the kernels; any other callable runs between the launches
+(_is_relu).  Inference (``eval()`` / no-grad) runs entirely on
 the fused kernels; under autograd the GEMMs run as ``MaskedLinearFn`` (forward / input-gradient / weight-gradient
 kernels) and BatchNorm (train() statistics), dropout and the context GLU gate are torch ops between them.
 Anything else raises instead of silently taking another path.
@@ -231,9 +232,17 @@ def _bn_through_torch(block, inputs):
     return block.training or _records(block, inputs)
 
 
+def _is_relu(activation):
+    """The reference default (F.relu) is fused into the GEMM kernels (prologue / epilogue flags); any other callable
+    (`activation=torch.tanh`, F.elu, ...: made.py:302, resnet.py:16) runs as itself - an elementwise op on the device
+    tensor - between the layers' launches, and the ReLU-only fast paths (row-resident / windowed inverse, one-launch
+    coupling conditioner) step aside for the general ones."""
+    return activation is F.relu or activation is torch.relu
+
+
 def _check_activation(activation):
-    if activation is not F.relu and activation is not torch.relu:
-        raise NotImplementedError('only the reference default activation (F.relu) is fused into the kernels')
+    if not callable(activation):
+        raise TypeError('activation must be callable')
 
 
 class MaskedFeedforwardBlock(nn.Module):
@@ -256,9 +265,10 @@ class MaskedFeedforwardBlock(nn.Module):
         if context is not None:
             raise NotImplementedError()
         dropping = self.training and self.dropout.p > 0
-        if dropping or _records(self, inputs) or (self.batch_norm is not None and self.training):
+        if not _is_relu(self.activation) or dropping or _records(self, inputs) or \
+                (self.batch_norm is not None and self.training):
             temps = inputs if self.batch_norm is None else self.batch_norm(inputs)
-            return self.dropout(torch.relu(self.linear.fused(temps)))
+            return self.dropout(self.activation(self.linear.fused(temps)))
         sc, sh = _bn_scale_shift(self.batch_norm) if self.batch_norm is not None else (None, None)
         return self.linear.fused(inputs, in_scale=sc, in_shift=sh, relu_out=True)
 
@@ -293,6 +303,16 @@ class MaskedResidualBlock(nn.Module):
 
     def forward(self, inputs, context=None):
         s0 = h0 = s1 = h1 = None
+        if not _is_relu(self.activation):
+            # general activation (made.py:268-284 op for op): the callable between the layers' launches
+            temps = self.batch_norm_layers[0](inputs) if self.use_batch_norm else inputs
+            temps = self.linear_layers[0].fused(self.activation(temps))
+            if self.use_batch_norm:
+                temps = self.batch_norm_layers[1](temps)
+            temps = self.dropout(self.activation(temps))
+            if context is None:
+                return self.linear_layers[1].fused(temps, residual=inputs)
+            return inputs + self.linear_layers[1].fused(temps) * torch.sigmoid(self.context_layer(context))
         if self.training and self.dropout.p > 0:
             # drop(act(BN1?(.))) in train() mode (made.py:275-278): torch's dropout between the two layers
             bn = self.batch_norm_layers if self.use_batch_norm else (lambda t: t, lambda t: t)
@@ -359,6 +379,8 @@ class MADE(nn.Module):
         if any(b.training and b.dropout.p > 0 for b in self.blocks):
             raise NotImplementedError('dropout is active (train() mode): the inverse kernels evaluate the network '
                                       'without it - call eval()')
+        if not self.relu_only():
+            raise NotImplementedError('the incremental inverse kernels fuse ReLU; other activations take the D-pass loop')
         steps = [(self.initial_layer, 'x', 'h0', None, False, False, None)]
         cur = 'h0'
         for i, block in enumerate(self.blocks):
@@ -370,6 +392,9 @@ class MADE(nn.Module):
                 steps.append((block.linear, cur, 'h%d' % (i + 1), None, False, True, block.batch_norm))
             cur = 'h%d' % (i + 1)
         return steps, cur
+
+    def relu_only(self):
+        return all(_is_relu(b.activation) for b in self.blocks)
 
     def hidden_degrees(self):
         """Sorted MADE degrees that occur on any hidden unit."""
@@ -400,6 +425,8 @@ class MADE(nn.Module):
         network is outside its scope: hidden units must be in degree order in every layer (the non-random masks
         with hidden_features <= features - 1), BatchNorm in eval mode only, the step structure of hidden_program()."""
         kind = kind or ('affine' if num_bins is None else 'rq')
+        if not self.relu_only():
+            return None
         steps, _ = self.hidden_program()
         layers = [st[0] for st in steps] + [self.final_layer]
         key = (kind,) + tuple((l.weight._version, l.weight.data_ptr(), None if l.bias is None else l.bias._version,

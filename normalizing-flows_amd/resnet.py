@@ -9,7 +9,7 @@ from torch import nn
 from torch.nn import functional as F, init
 
 from . import _lib
-from .made import DenseLinear, _bn_scale_shift, _bn_through_torch, _check_activation
+from .made import DenseLinear, _bn_scale_shift, _bn_through_torch, _check_activation, _is_relu
 
 
 class ResidualBlock(nn.Module):
@@ -33,6 +33,16 @@ class ResidualBlock(nn.Module):
 
     def forward(self, inputs, context=None):
         s0 = h0 = s1 = h1 = None
+        if not _is_relu(self.activation):
+            # general activation (resnet.py:38-57 op for op): the callable between the layers' launches
+            temps = self.batch_norm_layers[0](inputs) if self.use_batch_norm else inputs
+            temps = self.linear_layers[0].fused(self.activation(temps))
+            if self.use_batch_norm:
+                temps = self.batch_norm_layers[1](temps)
+            temps = self.dropout(self.activation(temps))
+            if context is None:
+                return self.linear_layers[1].fused(temps, residual=inputs)
+            return inputs + self.linear_layers[1].fused(temps) * torch.sigmoid(self.context_layer(context))
         if self.training and self.dropout.p > 0:
             # drop(act(BN1?(.))) in train() mode (resnet.py:44-50): torch's dropout between the two layers
             bn = self.batch_norm_layers if self.use_batch_norm else (lambda t: t, lambda t: t)
@@ -108,7 +118,7 @@ class ResidualNet(nn.Module):
         hidden width a multiple of 32 up to 128."""
         return (context is None and self.context_features is None and not self.records_grad(inputs)
                 and not any(b.training and (b.use_batch_norm or b.dropout.p > 0) for b in self.blocks)
-                and all(b.activation in (F.relu, torch.relu) for b in self.blocks)
+                and all(_is_relu(b.activation) for b in self.blocks)
                 and _lib.resnet_hidden_supported(self.initial_layer.in_features, self.hidden_features))
 
     def forward_hidden_columns(self, inputs, columns):

@@ -312,7 +312,7 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         if self._recording(inputs):
             _check_2d(inputs, net.initial_layer.in_features)
             return self._inverse_autograd(inputs, context)
-        if not self._fusable() or (context is not None and not (ROW_RESIDENT_INVERSE and net.inverse_rows_pack(self.num_bins, self.tails))):
+        if not net.relu_only() or not self._fusable() or (context is not None and not (ROW_RESIDENT_INVERSE and net.inverse_rows_pack(self.num_bins, self.tails))):
             return super().inverse(inputs, context)
         D = net.initial_layer.in_features
         _check_2d(inputs, D)

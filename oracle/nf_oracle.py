@@ -201,8 +201,8 @@ def _bn_eval(sd, name, x, eps=1e-3):
                         sd[name + '.weight'], sd[name + '.bias'], False, 0.0, eps)
 
 
-def made_forward(sd, x, prefix='', context=None):
-    """MADE.forward in eval mode (dropout off, BN uses running stats), relu activation.
+def made_forward(sd, x, prefix='', context=None, activation=F.relu):
+    """MADE.forward in eval mode (dropout off, BN uses running stats); `activation` as the constructor argument.
     made.py:352-359 with blocks :196-207 / :268-284.  Block kind, BN and context layers
     are discovered from the state_dict keys."""
     p = prefix
@@ -217,11 +217,11 @@ def made_forward(sd, x, prefix='', context=None):
             bn = b + 'batch_norm_layers.0.weight' in sd
             if bn:
                 t = _bn_eval(sd, b + 'batch_norm_layers.0', t)
-            t = F.relu(t)
+            t = activation(t)
             t = _masked_linear(sd, b + 'linear_layers.0', t)
             if bn:
                 t = _bn_eval(sd, b + 'batch_norm_layers.1', t)
-            t = F.relu(t)
+            t = activation(t)
             t = _masked_linear(sd, b + 'linear_layers.1', t)
             if context is not None:
                 c = F.linear(context, sd[b + 'context_layer.weight'], sd[b + 'context_layer.bias'])
@@ -231,7 +231,7 @@ def made_forward(sd, x, prefix='', context=None):
             t = h
             if b + 'batch_norm.weight' in sd:
                 t = _bn_eval(sd, b + 'batch_norm', t)
-            h = F.relu(_masked_linear(sd, b + 'linear', t))
+            h = activation(_masked_linear(sd, b + 'linear', t))
         else:
             break
         i += 1
@@ -267,19 +267,19 @@ def _rq_ar_elementwise(x, params, num_bins, tail_bound, inverse, mins, return_bi
 
 
 def rq_autoregressive_forward(sd, x, num_bins, tail_bound, prefix='autoregressive_net.',
-                              mins=(1e-3, 1e-3, 1e-3), return_bins=False, context=None):
+                              mins=(1e-3, 1e-3, 1e-3), return_bins=False, context=None, activation=F.relu):
     """One conditioner pass + elementwise forward.  transforms.py:488-491."""
-    params = made_forward(sd, x, prefix, context)
+    params = made_forward(sd, x, prefix, context, activation)
     return _rq_ar_elementwise(x, params, num_bins, tail_bound, False, mins, return_bins)
 
 
 def rq_autoregressive_inverse(sd, z, num_bins, tail_bound, prefix='autoregressive_net.',
-                              mins=(1e-3, 1e-3, 1e-3), context=None):
+                              mins=(1e-3, 1e-3, 1e-3), context=None, activation=F.relu):
     """D sequential full passes starting from zeros.  transforms.py:493-500."""
     out = torch.zeros_like(z)
     lad = None
     for _ in range(int(np.prod(z.shape[1:]))):
-        params = made_forward(sd, out, prefix, context)
+        params = made_forward(sd, out, prefix, context, activation)
         out, lad = _rq_ar_elementwise(z, params, num_bins, tail_bound, True, mins)
     return out, lad
 
@@ -307,7 +307,7 @@ def affine_autoregressive_inverse(sd, z, prefix='autoregressive_net.', context=N
 
 
 # --------------------------------------------------------------------------- coupling
-def residual_net_forward(sd, x, prefix='transform_net.', context=None):
+def residual_net_forward(sd, x, prefix='transform_net.', context=None, activation=F.relu):
     """Dense residual MLP in eval mode.  resnet.py:90-100, block :38-57."""
     p = prefix
     if context is not None:
@@ -320,11 +320,11 @@ def residual_net_forward(sd, x, prefix='transform_net.', context=None):
         t = h
         if bn:
             t = _bn_eval(sd, b + 'batch_norm_layers.0', t)
-        t = F.relu(t)
+        t = activation(t)
         t = F.linear(t, sd[b + 'linear_layers.0.weight'], sd[b + 'linear_layers.0.bias'])
         if bn:
             t = _bn_eval(sd, b + 'batch_norm_layers.1', t)
-        t = F.relu(t)
+        t = activation(t)
         t = F.linear(t, sd[b + 'linear_layers.1.weight'], sd[b + 'linear_layers.1.bias'])
         if context is not None:
             c = F.linear(context, sd[b + 'context_layer.weight'], sd[b + 'context_layer.bias'])

@@ -208,6 +208,38 @@ def gen_made():
              scale=-1.0 if scale is None else scale, **rows)
 
 
+def gen_activations():
+    """MADE / ResidualNet built with activations other than the default ReLU (made.py:302, resnet.py:66)."""
+    for name, act in [('tanh', torch.tanh), ('elu', torch.nn.functional.elu)]:
+        for tag, kw in [('res', dict()), ('ffbn', dict(use_residual_blocks=False, use_batch_norm=True))]:
+            torch.manual_seed(13)
+            net = made.MADE(features=6, hidden_features=16, output_multiplier=23, activation=act, **kw)
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.normal_(0, 0.5)
+                    m.running_var.uniform_(0.5, 2.0)
+            with torch.no_grad():
+                for p_ in net.parameters():
+                    p_.mul_(1.5)
+            net.eval()
+            x = torch.randn(32, 6)
+            with torch.no_grad():
+                y32 = net(x)
+                y64 = net.double()(x.double())
+            net.float()
+            save('made_small_%s_%s' % (tag, name), x=x, y32=y32, y64=y64, **sd_np(net.state_dict(), 'sd/'))
+        torch.manual_seed(14)
+        rn = resnet.ResidualNet(5, 12, hidden_features=32, num_blocks=2, activation=act).eval()
+        with torch.no_grad():
+            for p_ in rn.parameters():
+                p_.mul_(1.5)
+            x = torch.randn(32, 5)
+            y32 = rn(x)
+            y64 = rn.double()(x.double())
+        rn.float()
+        save('resnet_small_%s' % name, x=x, y32=y32, y64=y64, **sd_np(rn.state_dict(), 'sd/'))
+
+
 # ======================================================================= F3: RQ-AR layers
 def rq_ar_ref(D, H, K, T, sd):
     t = transforms.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
@@ -491,6 +523,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'maf_training':
         gen_maf_training()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'activations':
+        gen_activations()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'unconditional':
         gen_unconditional_coupling()
         sys.exit(0)
@@ -501,3 +536,4 @@ if __name__ == '__main__':
     gen_maf()
     gen_maf_training()
     gen_unconditional_coupling()
+    gen_activations()

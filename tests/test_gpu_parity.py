@@ -186,6 +186,75 @@ def test_made_small_golden(nf, tag, kw):
     assert rel_err(y.cpu(), fx['y64']) < TOL
 
 
+ACTS = {'tanh': torch.tanh, 'elu': torch.nn.functional.elu}
+
+
+@pytest.mark.parametrize('act', ['tanh', 'elu'])
+def test_activations_other_than_relu_golden(nf, act):
+    """`activation=` other than the fused ReLU (reference made.py:302, resnet.py:66), against the reference's outputs;
+    then the whole transform with such a conditioner: forward, D-pass inverse and gradients against the oracle."""
+    for tag, kw in [('res', {}), ('ffbn', dict(use_residual_blocks=False, use_batch_norm=True))]:
+        fx = load_golden('made_small_%s_%s' % (tag, act))
+        net = nf.MADE(features=6, hidden_features=16, output_multiplier=23, activation=ACTS[act], **kw)
+        net.load_state_dict(golden_state_dict(fx), strict=True)
+        net = net.cuda().eval()
+        with torch.no_grad():
+            y = net(dev(fx['x']))
+        assert rel_err(y.cpu(), fx['y64']) < TOL
+    fx = load_golden('resnet_small_' + act)
+    rn = nf.ResidualNet(5, 12, hidden_features=32, num_blocks=2, activation=ACTS[act])
+    rn.load_state_dict(golden_state_dict(fx), strict=True)
+    rn = rn.cuda().eval()
+    with torch.no_grad():
+        assert rel_err(rn(dev(fx['x'])).cpu(), fx['y64']) < TOL
+
+    D, H, K, B = 6, 16, 8, 64
+    t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        features=D, hidden_features=H, num_bins=K, tails='linear', tail_bound=3.0, activation=ACTS[act])
+    sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=21, scale=0.15)
+    t.load_state_dict(sd, strict=True)
+    t = t.cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, D, generator=g) * 1.5
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    want_y, want_l = O.rq_autoregressive_forward(sd64, x.double(), K, 3.0, activation=ACTS[act])
+    with torch.no_grad():
+        y, l = t(x.cuda())
+        xi, li = t.inverse(y)
+    f32_y, f32_ld = O.rq_autoregressive_forward(sd, x, K, 3.0, activation=ACTS[act])
+    assert rel_err(y.cpu(), want_y) <= max(TOL, 4 * rel_err(f32_y, want_y)), (rel_err(y.cpu(), want_y), rel_err(f32_y, want_y))
+    assert rel_err(l.cpu(), want_l) <= max(TOL, 4 * rel_err(f32_ld, want_l)), (rel_err(l.cpu(), want_l), rel_err(f32_ld, want_l))
+    want_x, want_li = O.rq_autoregressive_inverse(sd64, want_y, K, 3.0, activation=ACTS[act])
+    # fp32 floor of the D-pass inverse: the reference's own arithmetic in fp32 against fp64 on the same y
+    f32_x, f32_l = O.rq_autoregressive_inverse(sd, want_y.float(), K, 3.0, activation=ACTS[act])
+    ex, el = (xi.cpu().double() - want_x).abs(), (li.cpu().double() - want_li).abs()
+    assert ex.max().item() <= max(1e-4, 4 * (f32_x.double() - want_x).abs().max().item())
+    assert el.max().item() <= max(1e-3, 4 * (f32_l.double() - want_li).abs().max().item())
+    floor_frac = ((f32_x.double() - want_x).abs() > 1e-4).double().mean().item()
+    assert (ex > 1e-4).double().mean().item() <= 2 * floor_frac + 0.01
+    # gradients: our recorded graph (kernels + the activation's own autograd) vs fp64 autograd through the oracle
+    for p_ in t.parameters():
+        p_.grad = None
+    xg = x.cuda().requires_grad_(True)
+    y, l = t(xg)
+    (y.square().sum() * 0.5 - l.sum()).backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd64.items() if v.is_floating_point() and 'mask' not in k
+              and 'degrees' not in k}
+    full = dict(sd64)
+    full.update(leaves)
+    x64 = x.double().requires_grad_(True)
+    wy, wl = O.rq_autoregressive_forward(full, x64, K, 3.0, activation=ACTS[act])
+    (wy.square().sum() * 0.5 - wl.sum()).backward()
+    assert rel_err(xg.grad.cpu(), x64.grad) < 2e-3
+    named = dict(t.named_parameters())
+    checked = 0
+    for k, v in leaves.items():
+        if k in named and v.grad is not None:
+            assert rel_err(named[k].grad.cpu(), v.grad) < 2e-3, k        # the suite's fp32-vs-fp64 gradient bar
+            checked += 1
+    assert checked >= 6
+
+
 def test_made_context_golden(nf):
     fx = load_golden('made_small_ctx')
     net = nf.MADE(features=6, hidden_features=16, context_features=5, output_multiplier=2)

@@ -69,6 +69,22 @@ def test_made_small(tag):
     assert rel_err(O.made_forward(sd64, T(fx['x']).double()), fx['y64']) < 1e-14
 
 
+ACTS = {'tanh': torch.tanh, 'elu': torch.nn.functional.elu}
+
+
+@pytest.mark.parametrize('act', ['tanh', 'elu'])
+def test_activations_other_than_relu(act):
+    """made.py:302 / resnet.py:66 `activation=`: fixtures generated from the reference with tanh and elu."""
+    for tag in ['res', 'ffbn']:
+        fx = load_golden('made_small_%s_%s' % (tag, act))
+        sd = golden_state_dict(fx)
+        assert torch.equal(O.made_forward(sd, T(fx['x']), activation=ACTS[act]), T(fx['y32']))
+        assert not torch.equal(O.made_forward(sd, T(fx['x'])), T(fx['y32']))       # the activation matters
+    fx = load_golden('resnet_small_' + act)
+    y = O.residual_net_forward(golden_state_dict(fx), T(fx['x']), prefix='', activation=ACTS[act])
+    assert torch.equal(y, T(fx['y32']))
+
+
 def test_made_context():
     fx = load_golden('made_small_ctx')
     y = O.made_forward(golden_state_dict(fx), T(fx['x']), context=T(fx['context']))
