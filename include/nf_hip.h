@@ -389,6 +389,29 @@ int nf_rqs_inverse_bwd(const float* x_out, int64_t x_row_stride, const float* pa
                        int64_t B, int D, int K, int tails, double tail_bound, double min_bin_width,
                        double min_bin_height, double min_derivative, void* stream);
 
+/* Backward of nf_linear_spline_fwd / nf_quadratic_spline_fwd / nf_cubic_spline_fwd with feat_index = NULL (what
+ * autograd computes through models/splines/linear.py:35-94, quadratic.py:48-135, cubic.py:56-221 when the reference
+ * trains a flow of these families).  inverse = 0: x is the forward pass's input; inverse = 1: x is the inverse pass's
+ * OUTPUT and grad_y the gradient wrt it - the inverse is differentiated implicitly through the forward map at that
+ * point (for the cubic: through the quadratic the reference re-solves when |a| < 1e-3, cubic.py:191-198).
+ * grad_x [B,D] is the spline's direct part, grad_params [B, D*P] has contiguous rows.  torch.clamp(outputs, 0, 1) of
+ * the linear / quadratic forward passes no gradient to an output outside [0, 1], as in the reference.  LDS holds the
+ * parameters and their gradients of 256 elements: P <= 79. */
+int nf_linear_spline_bwd(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                         const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
+                         float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D,
+                         int K, int tails, double tail_bound, int inverse, void* stream);
+int nf_quadratic_spline_bwd(const float* x, int64_t x_row_stride, const float* params,
+                            int64_t param_row_stride, const float* grad_y, int64_t grad_y_row_stride,
+                            const float* grad_logabsdet, float* grad_x, int64_t grad_x_row_stride,
+                            float* grad_params, int64_t B, int D, int K, int tails, double tail_bound,
+                            double min_bin_width, double min_bin_height, int inverse, void* stream);
+int nf_cubic_spline_bwd(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                        double pre_div, const float* grad_y, int64_t grad_y_row_stride,
+                        const float* grad_logabsdet, float* grad_x, int64_t grad_x_row_stride,
+                        float* grad_params, int64_t B, int D, int K, int tails, double bound,
+                        double min_bin_width, double min_bin_height, int inverse, void* stream);
+
 /* ---- legacy Gaussian MAF layer, float64 (replaces models/flows.py:239-263 MaskedAutoregressiveFlow on
  *      models/made.py:11-89 SimpleMADE; the reference runs this class in float64 only) ---------------- */
 

@@ -48,6 +48,17 @@ _SIGNATURES = {
                               _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64,
                               _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
                               _c.c_double, _c.c_int, _c.c_void_p]),
+    'nf_linear_spline_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                        _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int,
+                                        _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_void_p]),
+    'nf_quadratic_spline_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                           _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int,
+                                           _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
+                                           _c.c_void_p]),
+    'nf_cubic_spline_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p,
+                                       _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                       _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
+                                       _c.c_void_p]),
     'nf_linear_spline_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p,
                                         _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
                                         _c.c_int, _c.c_double, _c.c_int, _c.c_void_p]),
@@ -898,6 +909,55 @@ def cubic_spline(x, params, num_bins, tails=None, bound=10.0, inverse=False, pre
                                        float(bound), float(min_bin_width), float(min_bin_height), int(inverse),
                                        _stream()), 'nf_cubic_spline_fwd')
     return out, logabsdet, bins
+
+
+def family_spline(kind, x, params, num_bins, tails=None, tail_bound=1.0, inverse=False, pre_div=1.0,
+                  min_bin_width=1e-3, min_bin_height=1e-3, **kw):
+    """The linear / quadratic / cubic spline by name (same arguments for all three; `tail_bound` is the cubic's
+    `bound`)."""
+    if kind == 'linear':
+        return linear_spline(x, params, num_bins, tails=tails, tail_bound=tail_bound, inverse=inverse, **kw)
+    if kind == 'quadratic':
+        return quadratic_spline(x, params, num_bins, tails=tails, tail_bound=tail_bound, inverse=inverse,
+                                min_bin_width=min_bin_width, min_bin_height=min_bin_height, **kw)
+    if kind == 'cubic':
+        return cubic_spline(x, params, num_bins, tails=tails, bound=tail_bound, inverse=inverse, pre_div=pre_div,
+                            min_bin_width=min_bin_width, min_bin_height=min_bin_height, **kw)
+    raise ValueError(kind)
+
+
+def family_spline_bwd(kind, x, params, grad_y, grad_lad, num_bins, tails=None, tail_bound=1.0, inverse=False,
+                      pre_div=1.0, min_bin_width=1e-3, min_bin_height=1e-3):
+    """(grad wrt the spline's input, grad_params) of nf_{linear,quadratic,cubic}_spline_fwd.  inverse: backward of the
+    inverse direction - `x` is then that pass's OUTPUT and grad_y the gradient wrt it."""
+    lib = load()
+    for t, n in ((x, 'inputs'), (params, 'params'), (grad_y, 'grad_y'), (grad_lad, 'grad_logabsdet')):
+        _dev(t, n)
+    B, D = x.shape
+    xp, xs = _rows(x, 'inputs')
+    pp, ps = _rows(params, 'params')
+    gyp, gys = _rows(grad_y, 'grad_y')
+    gx = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    gxp, gxs = _rows(gx, 'grad_x')
+    gparams = torch.empty_like(params)
+    gl = grad_lad.contiguous()
+    t = 1 if tails == 'linear' else 0
+    with torch.cuda.device(x.device):
+        if kind == 'linear':
+            code = lib.nf_linear_spline_bwd(xp, xs, pp, ps, gyp, gys, gl.data_ptr(), gxp, gxs, gparams.data_ptr(), B, D,
+                                            int(num_bins), t, float(tail_bound), int(inverse), _stream())
+        elif kind == 'quadratic':
+            code = lib.nf_quadratic_spline_bwd(xp, xs, pp, ps, gyp, gys, gl.data_ptr(), gxp, gxs, gparams.data_ptr(),
+                                               B, D, int(num_bins), t, float(tail_bound), float(min_bin_width),
+                                               float(min_bin_height), int(inverse), _stream())
+        elif kind == 'cubic':
+            code = lib.nf_cubic_spline_bwd(xp, xs, pp, ps, float(pre_div), gyp, gys, gl.data_ptr(), gxp, gxs,
+                                           gparams.data_ptr(), B, D, int(num_bins), t, float(tail_bound),
+                                           float(min_bin_width), float(min_bin_height), int(inverse), _stream())
+        else:
+            raise ValueError(kind)
+        _check(code, 'nf_%s_spline_bwd' % kind)
+    return gx, gparams
 
 
 def affine(x, params, layout, inverse=False, feat_index=None, out=None, logabsdet=None, accumulate=False,

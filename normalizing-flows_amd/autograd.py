@@ -109,6 +109,30 @@ class RqsFn(torch.autograd.Function):
         return gx, gparams, None, None, None, None, None, None
 
 
+class FamilySplineFn(torch.autograd.Function):
+    """The linear / quadratic / cubic spline (nf_*_spline_fwd) with its backward kernel (nf_*_spline_bwd), either
+    direction; cfg = dict(num_bins, tails, tail_bound, pre_div, min_bin_width, min_bin_height)."""
+
+    @staticmethod
+    def forward(ctx, x, params, kind, cfg, inverse=False):
+        y, lad, _ = _lib.family_spline(kind, x, params, inverse=inverse, **cfg)
+        ctx.save_for_backward(y if inverse else x, params)       # the inverse is differentiated at its OUTPUT
+        ctx.cfg = (kind, cfg, inverse)
+        return y, lad
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_lad):
+        x, params = ctx.saved_tensors
+        kind, cfg, inverse = ctx.cfg
+        if grad_y is None:
+            grad_y = torch.zeros_like(x)
+        if grad_lad is None:
+            grad_lad = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
+        gx, gparams = _lib.family_spline_bwd(kind, x, params, grad_y.contiguous(), grad_lad.contiguous(),
+                                             inverse=inverse, **cfg)
+        return gx, gparams, None, None, None
+
+
 class AffineFn(torch.autograd.Function):
     """nf_affine_fwd / nf_affine_bwd.  `feat_index` (int32, coupling) selects the transformed columns; the other
     columns of the output are the input's, and their gradient passes through."""

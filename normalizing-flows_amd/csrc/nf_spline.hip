@@ -154,7 +154,9 @@ struct RqsBwdArgs {
     int inverse;               // backward of the inverse direction (x = the inverse pass's OUTPUT, see rqs_bwd_eval)
 };
 
-template <int KT, int MAXV>
+// FAM 0: rational-quadratic (gradients overwrite the staged parameters in place); 1 / 2 / 3: linear / quadratic /
+// cubic family (nf_spline_families.h), whose reverse sweeps keep the parameters and write a second LDS region
+template <int KT, int MAXV, int FAM = 0>
 __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     const int nrows = (int)min((int64_t)a.rows_per_block, a.B - row0);
     const int E = nrows * D;
     float* stage = smem;
+    float* gout = FAM ? smem + ((kThreads * P + 4 + 3) & ~3) : smem;
     for (int it0 = 0; it0 < E; it0 += kThreads) {
         const int n = min(kThreads, E - it0);
         const int64_t g0 = (row0 * D + it0) * (int64_t)P;
@@ -185,7 +188,14 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
             const float xv = a.x[(row0 + r) * a.x_stride + d];
             const float gyv = a.gy[(row0 + r) * a.gy_stride + d];
             const float gl = a.glad[row0 + r];
-            a.gx[(row0 + r) * a.gx_stride + d] = rqs_bwd_eval<KT>(stage + shift + tid * P, xv, gyv, gl, a.c, a.inverse != 0);
+            float* ps = stage + shift + tid * P;
+            float* gs = gout + shift + tid * P;
+            float gxv;
+            if (FAM == 1) gxv = lin_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
+            else if (FAM == 2) gxv = quad_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
+            else if (FAM == 3) gxv = cubic_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
+            else gxv = rqs_bwd_eval<KT>(ps, xv, gyv, gl, a.c, a.inverse != 0);
+            a.gx[(row0 + r) * a.gx_stride + d] = gxv;
         }
         __syncthreads();
         // write the gradients of this span back: whole 16-byte vectors inside the span, scalars at its ends
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
             const int v = tid + i * kThreads;
             if (v >= nvec) continue;
             const int64_t f = a0 + 4 * (int64_t)v;
-            const float4 val = *reinterpret_cast<const float4*>(stage + 4 * v);
+            const float4 val = *reinterpret_cast<const float4*>(gout + 4 * v);
             if (a.vec_ok && f >= lo && f + 3 < hi) {
                 *reinterpret_cast<float4*>(a.gparams + f) = val;
             } else {
@@ -216,6 +226,24 @@ int launch_rqs_bwd_k(const RqsBwdArgs& a, int grid, size_t lds, hipStream_t s) {
     else if (per <= 12) hipLaunchKernelGGL((rqs_bwd_kernel<KT, 12>), dim3(grid), dim3(kThreads), lds, s, a);
     else if (per <= 25) hipLaunchKernelGGL((rqs_bwd_kernel<KT, 25>), dim3(grid), dim3(kThreads), lds, s, a);
     else return NF_ERR_SHAPE;
+    return nf_launch_status();
+}
+
+template <int FAM>
+int launch_family_bwd(const RqsBwdArgs& a, int grid, size_t lds, hipStream_t s) {
+    const int nv = (kThreads * a.c.P + 4 + 3) / 4;
+    const int per = (nv + kThreads - 1) / kThreads;
+    static unsigned long long raised[3] = {0, 0, 0};
+#define NF_FAM_BWD(MAXV)                                                                              \
+    do {                                                                                               \
+        if (int e = nf_raise_lds_cap((const void*)rqs_bwd_kernel<0, MAXV, FAM>, &raised[MAXV == 6 ? 0 : (MAXV == 12 ? 1 : 2)])) return e; \
+        hipLaunchKernelGGL((rqs_bwd_kernel<0, MAXV, FAM>), dim3(grid), dim3(kThreads), lds, s, a);     \
+    } while (0)
+    if (per <= 6) NF_FAM_BWD(6);
+    else if (per <= 12) NF_FAM_BWD(12);
+    else if (per <= 25) NF_FAM_BWD(25);
+    else return NF_ERR_SHAPE;
+#undef NF_FAM_BWD
     return nf_launch_status();
 }
 
@@ -617,6 +645,71 @@ extern "C" int nf_rqs_bwd(const float* x, int64_t x_row_stride, const float* par
     return rqs_bwd_impl(x, x_row_stride, params, param_row_stride, pre_div, grad_y, grad_y_row_stride, grad_logabsdet,
                         grad_x, grad_x_row_stride, grad_params, B, D, K, tails, tail_bound, min_bin_width,
                         min_bin_height, min_derivative, 0, stream);
+}
+
+// Backward of the linear / quadratic / cubic spline entry points, either direction (inverse: x = that pass's OUTPUT).
+template <int FAM>
+static int family_bwd(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                      const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet, float* grad_x,
+                      int64_t grad_x_row_stride, float* grad_params, int64_t B, int D, int K, int P, int tails,
+                      double tail_bound, double min_w, double min_h, int inverse, void* stream, double pre_div = 1.0,
+                      bool symmetric = false) {
+    if (B == 0) return NF_OK;
+    if (!x || !params || !grad_y || !grad_logabsdet || !grad_x || !grad_params) return NF_ERR_NULL;
+    if (param_row_stride != (int64_t)D * P) return NF_ERR_LAYOUT;
+    if (x_row_stride < D || grad_y_row_stride < D || grad_x_row_stride < D) return NF_ERR_LAYOUT;
+    RqsBwdArgs a;
+    a.x = x; a.x_stride = x_row_stride; a.params = params; a.n_param_floats = B * (int64_t)D * P;
+    a.gy = grad_y; a.gy_stride = grad_y_row_stride; a.glad = grad_logabsdet; a.gx = grad_x;
+    a.gx_stride = grad_x_row_stride; a.gparams = grad_params; a.B = B; a.D = D;
+    a.c = nf_make_rqs_const(K, tails, tail_bound, min_w, min_h, 1e-3, pre_div);
+    a.c.P = P;
+    if (symmetric) {
+        a.c.left = (float)-tail_bound;
+        a.c.right = (float)tail_bound;
+        a.c.span = (float)(2.0 * tail_bound);
+    }
+    a.rows_per_block = pick_rows_per_block(D, B);
+    a.vec_ok = (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0;
+    a.inverse = inverse;
+    const size_t lds = 2 * sizeof(float) * (size_t)((kThreads * P + 4 + 3) & ~3);     // parameters + gradients
+    if (lds > 160 * 1024) return NF_ERR_SHAPE;
+    const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
+    if (grid > 0x7fffffff) return NF_ERR_SHAPE;
+    return launch_family_bwd<FAM>(a, (int)grid, lds, (hipStream_t)stream);
+}
+
+extern "C" int nf_linear_spline_bwd(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                                    const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
+                                    float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D,
+                                    int K, int tails, double tail_bound, int inverse, void* stream) {
+    if (B < 0 || D <= 0 || K <= 0 || K > 64) return NF_ERR_SHAPE;
+    return family_bwd<1>(x, x_row_stride, params, param_row_stride, grad_y, grad_y_row_stride, grad_logabsdet, grad_x,
+                         grad_x_row_stride, grad_params, B, D, K, K, tails, tail_bound, 0.0, 0.0, inverse, stream);
+}
+
+extern "C" int nf_quadratic_spline_bwd(const float* x, int64_t x_row_stride, const float* params,
+                                       int64_t param_row_stride, const float* grad_y, int64_t grad_y_row_stride,
+                                       const float* grad_logabsdet, float* grad_x, int64_t grad_x_row_stride,
+                                       float* grad_params, int64_t B, int D, int K, int tails, double tail_bound,
+                                       double min_bin_width, double min_bin_height, int inverse, void* stream) {
+    if (B < 0 || D <= 0 || K < 2 || K > 32) return NF_ERR_SHAPE;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+    return family_bwd<2>(x, x_row_stride, params, param_row_stride, grad_y, grad_y_row_stride, grad_logabsdet, grad_x,
+                         grad_x_row_stride, grad_params, B, D, K, tails ? 2 * K - 1 : 2 * K + 1, tails, tail_bound,
+                         min_bin_width, min_bin_height, inverse, stream);
+}
+
+extern "C" int nf_cubic_spline_bwd(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                                   double pre_div, const float* grad_y, int64_t grad_y_row_stride,
+                                   const float* grad_logabsdet, float* grad_x, int64_t grad_x_row_stride,
+                                   float* grad_params, int64_t B, int D, int K, int tails, double bound,
+                                   double min_bin_width, double min_bin_height, int inverse, void* stream) {
+    if (B < 0 || D <= 0 || K <= 0 || K > 32 || !(bound > 0.0) || !(pre_div > 0.0)) return NF_ERR_SHAPE;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+    return family_bwd<3>(x, x_row_stride, params, param_row_stride, grad_y, grad_y_row_stride, grad_logabsdet, grad_x,
+                         grad_x_row_stride, grad_params, B, D, K, 2 * K + 2, tails, bound, min_bin_width,
+                         min_bin_height, inverse, stream, pre_div, true);
 }
 
 // Backward of nf_rqs_fwd(inverse = 1): x_out = the inverse pass's OUTPUT, grad_x_out / grad_logabsdet the gradients

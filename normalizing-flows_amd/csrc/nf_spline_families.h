@@ -269,3 +269,322 @@ __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, flo
     }
     bin = b;
 }
+
+// ===================================================================================================================
+// Backward of the three families (training: the reference differentiates linear.py / quadratic.py / cubic.py with
+// autograd).  p = the element's parameters in LDS (read only), g = its P-float gradient slot in LDS (written, and used
+// as the accumulator arrays of the reverse sweep).  Returns dL/dx.  Forward direction: x is the input, (gy, gl) the
+// gradients wrt y and wrt this element's log|dy/dx|.  Inverse direction (inv): x is the inverse pass's OUTPUT, (gy, gl)
+// the gradients wrt that output and wrt the inverse's logabsdet (= -log f'(x)); the result follows from the forward
+// map f by implicit differentiation - with A = (gy - gl * d(-log f')/dx ... ) / f' the gradient wrt the inverse's input
+// is A and the parameter gradient is that of the forward sweep run with upstream (-A, -gl) - which is what autograd
+// through the reference's closed-form roots evaluates, up to rounding.
+// Everything below is in the normalised coordinates t = (x - left) / span, o = (y - left) / span.
+// ===================================================================================================================
+
+template <class PT>
+__device__ __forceinline__ float lin_bwd_eval(PT p, float* g, float x, float gy, float gl, const RqsConst& a, bool inv) {
+    const int K = a.K;
+    if (a.tails && !(x >= a.left && x <= a.right)) {
+        for (int k = 0; k < K; ++k) g[k] = 0.0f;
+        return gy;
+    }
+    const float t = (x - a.left) / a.span;
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, p[k]);
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s += nf_exp(p[k] - m);
+    const float pos = t * (float)K;
+    int b = (int)floorf(pos);
+    b = b >= K ? K - 1 : (b < 0 ? 0 : b);
+    const float alpha = pos - (float)b;
+    float cb = 0.0f, pb = 0.0f;
+    for (int k = 0; k <= b; ++k) {
+        const float pk = nf_exp(p[k] - m) / s;
+        if (k < b) cb += pk; else pb = pk;
+    }
+    const float o = cb + alpha * pb;
+    const float fp = (float)K * pb;                       // dy/dx (the two spans cancel); d log f' / dx = 0 inside a bin
+    float A = 0.0f;
+    if (inv) {
+        A = gy / fp;
+        gy = -A;
+        gl = -gl;
+    } else if (!(o >= 0.0f && o <= 1.0f)) {
+        gy = 0.0f;                                        // torch.clamp(outputs, 0, 1) passes no gradient outside
+    }
+    const float go = gy * a.span;
+    const float S = go * o + gl;                          // sum_k g_pdf[k] * pdf[k]
+    for (int k = 0; k < K; ++k) {
+        const float pk = nf_exp(p[k] - m) / s;
+        const float gp = k < b ? go : (k == b ? go * alpha + gl / pb : 0.0f);
+        g[k] = pk * (gp - S);
+    }
+    return inv ? A : gy * fp;
+}
+
+template <class PT>
+__device__ __forceinline__ float quad_bwd_eval(PT p, float* g, float x, float gy, float gl, const RqsConst& a, bool inv) {
+    const int K = a.K, P = a.P;
+    if (a.tails && !(x >= a.left && x <= a.right)) {
+        for (int k = 0; k < P; ++k) g[k] = 0.0f;
+        return gy;
+    }
+    const PT uw = p;
+    const PT uh = p + K;
+    float* gw = g;                 // [K]   dL/d width_k, then dL/d uw_k
+    float* gE = g + K;             // [K-1] (tails) dL/d exp(uh_j)  |  [K+1] dL/d H_k
+    const float t = (x - a.left) / a.span;
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, uw[k]);
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s += nf_exp(uw[k] - m);
+    auto sm = [&](int k) { return nf_exp(uw[k] - m) / s; };
+    auto width = [&](int k) { return (k < 0 || k >= K) ? 0.0f : a.min_w + a.scale_w * sm(k); };
+    float cst = 0.0f, num = 0.0f, den = 1.0f;
+    if (a.tails) {
+        const float first = 0.5f * width(0), last = 0.5f * width(K - 1);
+        float mid = 0.0f;
+        for (int j = 0; j + 1 < K - 1; ++j) mid += ((nf_exp(uh[j]) + nf_exp(uh[j + 1])) / 2.0f) * width(j + 1);
+        num = 0.5f * first * nf_exp(uh[0]) + 0.5f * last * nf_exp(uh[K - 2]) + mid;
+        den = 1.0f - 0.5f * first - 0.5f * last;
+        cst = num / den;
+    }
+    auto H = [&](int k) {
+        if (!a.tails) return nf_exp(uh[k]);
+        return (k == 0 || k == K) ? cst : nf_exp(uh[k - 1]);
+    };
+    float area = 0.0f;
+    for (int k = 0; k < K; ++k) area += ((H(k) + H(k + 1)) / 2.0f) * width(k);
+    const float omh = 1.0f - a.min_h;
+    auto hgt = [&](int k) { return a.min_h + omh * (H(k) / area); };
+    // the forward-direction search at x (bin edges = the running sum of the widths, as in quad_eval<false>)
+    double accw = 0.0, accc = 0.0;
+    float loc0 = 0.0f, cdf0 = 0.0f, loc = 0.0f, w = 1.0f, c = 0.0f, hl = 1.0f, hr = 1.0f;
+    int b = 0;
+    float hk = hgt(0);
+    for (int k = 0; k < K; ++k) {
+        const float wk = width(k);
+        const float hk1 = hgt(k + 1);
+        accw += (double)wk;
+        accc += (double)(((hk + hk1) / 2.0f) * wk);
+        if (t >= loc0) { b = k; loc = loc0; w = wk; c = cdf0; hl = hk; hr = hk1; }
+        loc0 = (float)accw;
+        cdf0 = (float)accc;
+        hk = hk1;
+    }
+    const float alpha = (t - loc) / w;
+    const float dens = alpha * (hr - hl) + hl;
+    const float o = (0.5f * (hr - hl) * w) * (alpha * alpha) + (hl * w) * alpha + c;
+    const float fp = dens;                                 // do/dt = dy/dx
+    const float dldx = ((hr - hl) / (dens * w)) / a.span;
+    float A = 0.0f;
+    if (inv) {
+        A = (gy - gl * dldx) / fp;                         // the inverse's logabsdet is -log f'(x_out)
+        gy = -A;
+        gl = -gl;
+    } else if (!(o >= 0.0f && o <= 1.0f)) {
+        gy = 0.0f;
+    }
+    const float go = gy * a.span;
+    const float ga = go * w * dens + gl * (hr - hl) / dens;          // wrt alpha
+    const float gloc = -ga / w;
+    const float gwd = go * (0.5f * (hr - hl) * (alpha * alpha) + hl * alpha) - ga * alpha / w;
+    const float ghl = go * w * (alpha - 0.5f * (alpha * alpha)) + gl * (1.0f - alpha) / dens;
+    const float ghr = go * 0.5f * w * (alpha * alpha) + gl * alpha / dens;
+    const float gc = go;
+    // dL/d h_k (normalised knot heights), k = 0..K: through the cdf prefix and the bin's two knots
+    auto gh = [&](int k) {
+        float v = 0.0f;
+        if (k >= 1 && k - 1 < b) v += gc * 0.5f * width(k - 1);
+        if (k < b) v += gc * 0.5f * width(k);
+        if (k == b) v += ghl;
+        if (k == b + 1) v += ghr;
+        return v;
+    };
+    float sgh = 0.0f;
+    for (int k = 0; k <= K; ++k) sgh += gh(k) * H(k);
+    const float garea = -(omh / (area * area)) * sgh;
+    // dL/d H_k -> uh slots
+    float gcst = 0.0f;
+    for (int k = 0; k <= K; ++k) {
+        const float v = omh * gh(k) / area + garea * 0.5f * (width(k - 1) + width(k));
+        if (!a.tails) gE[k] = v;
+        else if (k == 0 || k == K) gcst += v;
+        else gE[k - 1] = v;
+    }
+    // dL/d width_k
+    for (int k = 0; k < K; ++k) {
+        float v = garea * 0.5f * (H(k) + H(k + 1));
+        if (k < b) v += gloc + gc * 0.5f * (hgt(k) + hgt(k + 1));
+        if (k == b) v += gwd;
+        gw[k] = v;
+    }
+    if (a.tails) {
+        const float gnum = gcst / den;
+        const float gden = -gcst * num / (den * den);
+        const float E0 = nf_exp(uh[0]), EL = nf_exp(uh[K - 2]);
+        gw[0] += -0.25f * gden + 0.25f * E0 * gnum;
+        gw[K - 1] += -0.25f * gden + 0.25f * EL * gnum;
+        gE[0] += 0.25f * width(0) * gnum;
+        gE[K - 2] += 0.25f * width(K - 1) * gnum;
+        for (int j = 0; j + 1 < K - 1; ++j) {
+            const float wj = width(j + 1);
+            gE[j] += gnum * 0.5f * wj;
+            gE[j + 1] += gnum * 0.5f * wj;
+            gw[j + 1] += gnum * 0.5f * (nf_exp(uh[j]) + nf_exp(uh[j + 1]));
+        }
+        for (int j = 0; j < K - 1; ++j) gE[j] *= nf_exp(uh[j]);
+    } else {
+        for (int k = 0; k <= K; ++k) gE[k] *= nf_exp(uh[k]);
+    }
+    // softmax of the widths
+    float S = 0.0f;
+    for (int k = 0; k < K; ++k) S += a.scale_w * gw[k] * sm(k);
+    for (int k = 0; k < K; ++k) gw[k] = sm(k) * (a.scale_w * gw[k] - S);
+    return inv ? A : gy * fp + gl * dldx;
+}
+
+template <class PT>
+__device__ __forceinline__ float cubic_bwd_eval(PT p, float* g, float x, float gy, float gl, const RqsConst& a, bool inv) {
+    const int K = a.K, P = a.P;
+    if (a.tails && !(x >= a.left && x <= a.right)) {
+        for (int k = 0; k < P; ++k) g[k] = 0.0f;
+        return gy;
+    }
+    const PT uw = p;
+    const PT uh = p + K;
+    const bool scaled = a.pre_div != 1.0f;
+    auto raw = [&](PT u, int k) { return scaled ? u[k] / a.pre_div : u[k]; };
+    const float t = (x - a.left) / a.span;
+    float mw = -INFINITY, mh = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        mw = fmaxf(mw, raw(uw, k));
+        mh = fmaxf(mh, raw(uh, k));
+    }
+    float sw = 0.0f, sh_ = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        sw += nf_exp(raw(uw, k) - mw);
+        sh_ += nf_exp(raw(uh, k) - mh);
+    }
+    auto smw = [&](int k) { return nf_exp(raw(uw, k) - mw) / sw; };
+    auto smh = [&](int k) { return nf_exp(raw(uh, k) - mh) / sh_; };
+    auto width = [&](int k) { return a.min_w + a.scale_w * smw(k); };
+    auto height = [&](int k) { return a.min_h + a.scale_h * smh(k); };
+    double accw = 0.0;
+    float cw0 = 0.0f, lw = 0.0f;
+    int b = 0;
+    for (int k = 0; k < K; ++k) {
+        accw += (double)width(k);
+        if (t >= cw0) { b = k; lw = cw0; }
+        cw0 = (float)accw;
+    }
+    const float wb = width(b), hb = height(b), sb = hb / wb;
+    float w0 = 1.0f, h0 = 1.0f, s0 = 1.0f, w1 = 1.0f, h1 = 1.0f, s1 = 1.0f, sigl = 0.0f, sigr = 0.0f;
+    float dl, dr;
+    auto interior = [&](float wa, float sa, float wc, float sc) {
+        return 2.0f * fminf(fminf(sa, sc), 0.5f * (wc * sa + wa * sc) / (wa + wc));       // slopes are positive
+    };
+    if (b == 0) {
+        sigl = 1.0f / (1.0f + nf_exp(-p[2 * K]));
+        dl = sigl * 3.0f * sb;
+    } else {
+        w0 = width(b - 1); h0 = height(b - 1); s0 = h0 / w0;
+        dl = interior(w0, s0, wb, sb);
+    }
+    if (b == K - 1) {
+        sigr = 1.0f / (1.0f + nf_exp(-p[2 * K + 1]));
+        dr = sigr * 3.0f * sb;
+    } else {
+        w1 = width(b + 1); h1 = height(b + 1); s1 = h1 / w1;
+        dr = interior(wb, sb, w1, s1);
+    }
+    const float ca = (dl + dr - 2.0f * sb) / (wb * wb);
+    const float cb = (3.0f * sb - 2.0f * dl - dr) / wb;
+    const float cc = dl;
+    const float s = t - lw;
+    const float Dv = 3.0f * ca * (s * s) + 2.0f * cb * s + cc;        // do/dt = dy/dx
+    const float D2 = 6.0f * ca * s + 2.0f * cb;
+    float g_ca, g_cb, g_cc, g_d, g_lw, ret;
+    if (!inv) {
+        const float go = gy * a.span;
+        const float gs = go * Dv + gl * D2 / Dv;
+        ret = gs / a.span;
+        g_lw = -gs;
+        g_ca = go * (s * s * s) + gl * 3.0f * (s * s) / Dv;
+        g_cb = go * (s * s) + gl * 2.0f * s / Dv;
+        g_cc = go * s + gl / Dv;
+        g_d = go;
+    } else {
+        // the reference solves the cubic, or - for |a| < 1e-3 - the quadratic b s^2 + c s + d = t (cubic.py:191-198)
+        const bool quad = fabsf(ca) < 1e-3f;
+        const float Gp = quad ? 2.0f * cb * s + cc : Dv;
+        const float s3 = quad ? 0.0f : s * s * s;
+        const float gon = gy * a.span;
+        const float gs = gon - gl * D2 / Dv;
+        const float q = gs / Gp;
+        ret = q / a.span;
+        g_lw = gon;
+        g_ca = -gl * 3.0f * (s * s) / Dv - q * s3;
+        g_cb = -gl * 2.0f * s / Dv - q * (s * s);
+        g_cc = -gl / Dv - q * s;
+        g_d = -q;
+    }
+    // coefficients -> knot derivatives, slope and width of bin b
+    const float iw = 1.0f / wb, iw2 = iw * iw;
+    const float g_dl = g_ca * iw2 - 2.0f * g_cb * iw + g_cc;
+    const float g_dr = g_ca * iw2 - g_cb * iw;
+    float g_sb = -2.0f * g_ca * iw2 + 3.0f * g_cb * iw;
+    float g_wb = -2.0f * ca * g_ca * iw - cb * g_cb * iw;
+    float g_w0 = 0.0f, g_w1 = 0.0f, g_s0 = 0.0f, g_s1 = 0.0f, g_ul = 0.0f, g_ur = 0.0f;
+    if (b == 0) {
+        g_ul = g_dl * 3.0f * sb * sigl * (1.0f - sigl);
+        g_sb += g_dl * 3.0f * sigl;
+    } else {
+        const float m2 = 0.5f * (wb * s0 + w0 * sb) / (w0 + wb), gm = 2.0f * g_dl;
+        if (fminf(s0, sb) <= m2) {
+            if (s0 <= sb) g_s0 += gm; else g_sb += gm;
+        } else {
+            const float id = 1.0f / (w0 + wb);
+            g_s0 += gm * 0.5f * wb * id;
+            g_sb += gm * 0.5f * w0 * id;
+            g_wb += gm * (0.5f * s0 - m2) * id;
+            g_w0 += gm * (0.5f * sb - m2) * id;
+        }
+    }
+    if (b == K - 1) {
+        g_ur = g_dr * 3.0f * sb * sigr * (1.0f - sigr);
+        g_sb += g_dr * 3.0f * sigr;
+    } else {
+        const float m2 = 0.5f * (w1 * sb + wb * s1) / (wb + w1), gm = 2.0f * g_dr;
+        if (fminf(sb, s1) <= m2) {
+            if (sb <= s1) g_sb += gm; else g_s1 += gm;
+        } else {
+            const float id = 1.0f / (wb + w1);
+            g_sb += gm * 0.5f * w1 * id;
+            g_s1 += gm * 0.5f * wb * id;
+            g_wb += gm * (0.5f * s1 - m2) * id;
+            g_w1 += gm * (0.5f * sb - m2) * id;
+        }
+    }
+    const float g_hb = g_sb * iw;
+    g_wb += -g_sb * sb * iw;
+    float g_h0 = 0.0f, g_h1 = 0.0f;
+    if (b > 0) { g_h0 = g_s0 / w0; g_w0 += -g_s0 * s0 / w0; }
+    if (b < K - 1) { g_h1 = g_s1 / w1; g_w1 += -g_s1 * s1 / w1; }
+    // back through min + scale * softmax(u / pre_div) of the widths and of the heights
+    auto gwk = [&](int k) { return (k < b ? g_lw : 0.0f) + (k == b - 1 ? g_w0 : 0.0f) + (k == b ? g_wb : 0.0f) + (k == b + 1 ? g_w1 : 0.0f); };
+    auto ghk = [&](int k) { return (k < b ? g_d : 0.0f) + (k == b - 1 ? g_h0 : 0.0f) + (k == b ? g_hb : 0.0f) + (k == b + 1 ? g_h1 : 0.0f); };
+    float Sw = 0.0f, Sh = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        Sw += a.scale_w * gwk(k) * smw(k);
+        Sh += a.scale_h * ghk(k) * smh(k);
+    }
+    for (int k = 0; k < K; ++k) {
+        g[k] = smw(k) * (a.scale_w * gwk(k) - Sw) / a.pre_div;
+        g[K + k] = smh(k) * (a.scale_h * ghk(k) - Sh) / a.pre_div;
+    }
+    g[2 * K] = g_ul;
+    g[2 * K + 1] = g_ur;
+    return ret;
+}

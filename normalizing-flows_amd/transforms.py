@@ -105,7 +105,10 @@ class AutoregressiveTransform(nn.Module):
         return outputs, logabsdet
 
     def _forward_autograd(self, inputs, context):
-        raise NotImplementedError('this transform has no backward kernels: call under torch.no_grad()')
+        """Training path: conditioner through MaskedLinearFn, the elementwise transform through the subclass's
+        autograd.Function (the parameter tensor is materialised: its backward needs it)."""
+        params = self.autoregressive_net(inputs.contiguous(), context)
+        return self._elementwise_autograd(inputs.contiguous(), params, inverse=False)
 
     def _inverse_autograd(self, inputs, context):
         """The sampling direction under autograd (what the reference's default reverse-KL loss differentiates,
@@ -388,6 +391,10 @@ class MaskedPiecewiseLinearAutoregressiveTransform(AutoregressiveTransform):
         _lib.linear_spline(inputs, params, self.num_bins, tails=None, inverse=inverse, out=outputs,
                            logabsdet=logabsdet)
 
+    def _elementwise_autograd(self, inputs, params, inverse):
+        from .autograd import FamilySplineFn
+        return FamilySplineFn.apply(inputs, params.contiguous(), 'linear', dict(num_bins=self.num_bins), bool(inverse))
+
     def inverse(self, inputs, context=None):
         return self._inverse_via_rows(inputs, context, 'linear', self.num_bins, None,
                                       lambda pi, z, out, hid, ctx: _lib.made_family_inverse_rows(
@@ -431,6 +438,12 @@ class MaskedPiecewiseQuadraticAutoregressiveTransform(AutoregressiveTransform):
                               inverse=inverse, out=outputs, logabsdet=logabsdet, min_bin_width=self.min_bin_width,
                               min_bin_height=self.min_bin_height)
 
+    def _elementwise_autograd(self, inputs, params, inverse):
+        from .autograd import FamilySplineFn
+        cfg = dict(num_bins=self.num_bins, tails=self.tails, tail_bound=self.tail_bound,
+                   min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height)
+        return FamilySplineFn.apply(inputs, params.contiguous(), 'quadratic', cfg, bool(inverse))
+
     def inverse(self, inputs, context=None):
         return self._inverse_via_rows(inputs, context, 'quadratic', self.num_bins, self.tails,
                                       lambda pi, z, out, hid, ctx: _lib.made_family_inverse_rows(
@@ -460,6 +473,11 @@ class MaskedPiecewiseCubicAutoregressiveTransform(AutoregressiveTransform):
     def _elementwise(self, inputs, params, outputs, logabsdet, inverse):
         _lib.cubic_spline(inputs, params, self.num_bins, tails=None, bound=10.0, inverse=inverse, out=outputs,
                           logabsdet=logabsdet)
+
+    def _elementwise_autograd(self, inputs, params, inverse):
+        from .autograd import FamilySplineFn
+        return FamilySplineFn.apply(inputs, params.contiguous(), 'cubic', dict(num_bins=self.num_bins, tail_bound=10.0),
+                                    bool(inverse))
 
     def inverse(self, inputs, context=None):
         return self._inverse_via_rows(inputs, context, 'cubic', self.num_bins, None,
@@ -740,6 +758,21 @@ class PiecewiseCubicCouplingTransform(CouplingTransform):
 
     def _transform_dim_multiplier(self):
         return self.num_bins * 2 + 2
+
+    def _run_autograd(self, inputs, context, inverse):
+        """Training path, either direction: transformed columns gathered, cubic spline + its backward kernel as
+        FamilySplineFn (nf_cubic_spline_fwd / _bwd with the coupling pre-divisor), scattered back."""
+        from .autograd import FamilySplineFn
+        if self.tails not in (None, 'linear'):
+            raise RuntimeError('{} tails are not implemented.'.format(self.tails))
+        pre_div = np.sqrt(self.transform_net.hidden_features) if hasattr(self.transform_net, 'hidden_features') else 1.0
+        identity_split = inputs[:, self.identity_features].contiguous()
+        params = self.transform_net(identity_split, context).contiguous()
+        xt = inputs.index_select(1, self.transform_features).contiguous()
+        cfg = dict(num_bins=self.num_bins, tails=self.tails, tail_bound=10.0 if self.tails is None else self.tail_bound,
+                   pre_div=float(pre_div), min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height)
+        yt, logabsdet = FamilySplineFn.apply(xt, params, 'cubic', cfg, bool(inverse))
+        return inputs.index_copy(1, self.transform_features, yt), logabsdet
 
     def _coupling_elementwise(self, inputs, transform_params, outputs, logabsdet, inverse):
         pre_div = np.sqrt(self.transform_net.hidden_features) if hasattr(self.transform_net, 'hidden_features') else 1.0
