@@ -184,8 +184,12 @@ __device__ __forceinline__ void rqs_eval(PT p, float x, const RqsConst& a, float
     // slopes at the two knots of the bin
     float u0, u1;
     if (a.tails) {
-        u0 = bin == 0 ? a.tail_const : ud[(bin - 1) * STRIDE];
-        u1 = bin == K - 1 ? a.tail_const : ud[bin * STRIDE];
+        // both reads unconditional at clamped indices, then a VALUE select: a select between the address of the
+        // constant and an LDS address would turn these into flat loads, which wait on every outstanding global load
+        const float v0 = ud[(bin == 0 ? 0 : bin - 1) * STRIDE];
+        const float v1 = ud[(bin == K - 1 ? K - 2 : bin) * STRIDE];
+        u0 = bin == 0 ? a.tail_const : v0;
+        u1 = bin == K - 1 ? a.tail_const : v1;
     } else {
         u0 = ud[bin * STRIDE];
         u1 = ud[(bin + 1) * STRIDE];
@@ -286,8 +290,10 @@ __device__ __forceinline__ void rqs_inverse_pair(PT p, float x, const RqsConst& 
 
     float u0, u1;
     if (a.tails) {
-        u0 = b == 0 ? a.tail_const : ud[(b - 1) * STRIDE];
-        u1 = b == K - 1 ? a.tail_const : ud[b * STRIDE];
+        const float v0 = ud[(b == 0 ? 0 : b - 1) * STRIDE];
+        const float v1 = ud[(b == K - 1 ? K - 2 : b) * STRIDE];
+        u0 = b == 0 ? a.tail_const : v0;
+        u1 = b == K - 1 ? a.tail_const : v1;
     } else {
         u0 = ud[b * STRIDE];
         u1 = ud[(b + 1) * STRIDE];
@@ -386,8 +392,9 @@ __device__ __forceinline__ float rqs_bwd_eval(float* __restrict__ p, float x, fl
     int i0, i1;                      // index into ud, -1 = pinned boundary constant
     if (a.tails) { i0 = bin == 0 ? -1 : bin - 1; i1 = bin == K - 1 ? -1 : bin; }
     else { i0 = bin; i1 = bin + 1; }
-    const float u0 = i0 < 0 ? a.tail_const : ud[i0];
-    const float u1 = i1 < 0 ? a.tail_const : ud[i1];
+    const float v0 = ud[i0 < 0 ? 0 : i0], v1 = ud[i1 < 0 ? 0 : i1];          // value selects, not address selects
+    const float u0 = i0 < 0 ? a.tail_const : v0;
+    const float u1 = i1 < 0 ? a.tail_const : v1;
     const float d0 = a.min_d + softplus_f(u0);
     const float d1 = a.min_d + softplus_f(u1);
 

@@ -41,19 +41,67 @@ struct RqsArgs {
     int vec_ok;                // params base 16-byte aligned
 };
 
-// Copies params floats [a0, a0 + 4*nvec) into registers (16-byte loads where the whole vector is in range).
-__device__ __forceinline__ float4 load_vec(const float* __restrict__ params, int64_t f, int64_t total, int vec_ok) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < 0) return v;
-    if (vec_ok && f + 3 < total) {
-        v = *reinterpret_cast<const float4*>(params + f);
-    } else {
-        if (f < total) v.x = params[f];
-        if (f + 1 < total) v.y = params[f + 1];
-        if (f + 2 < total) v.z = params[f + 2];
-        if (f + 3 < total) v.w = params[f + 3];
+// Staging of parameter spans (shared by the forward and backward kernels).  The block's parameters are one contiguous
+// run of floats starting at gblk = row0 * D * P; every span of 256 elements starts 256 * P floats after the previous
+// one, so all spans of a block sit at the same offset `shift` (0..3 floats) from a 16-byte boundary.  With a 16-byte
+// aligned base the spans are fetched as 16-byte pieces through a buffer descriptor whose range check returns zeros
+// past the end of the array (the last span may round up past it by < 4 floats) - no per-piece branches; an unaligned
+// base (never what torch hands over, but legal at the C ABI) takes scalar loads straight into LDS.
+// e / D for 0 <= e < 2^24 without the integer-division sequence: float estimate, corrected by one either way
+__device__ __forceinline__ int div_small(int e, int D, float inv_d) {
+    int r = (int)((float)e * inv_d);
+    r -= (r * D > e) ? 1 : 0;
+    r += ((r + 1) * D <= e) ? 1 : 0;
+    return r;
+}
+
+struct SpanStage {
+    __amdgpu_buffer_rsrc_t rsrc;
+    const float* base;          // params + gblk (scalar path)
+    int shift;                  // floats between the 16-byte boundary below gblk and gblk
+    int vec;
+};
+
+__device__ __forceinline__ SpanStage span_stage_init(const float* params, int64_t n_param_floats, int64_t gblk, int vec_ok) {
+    SpanStage st;
+    const int64_t ablk = gblk & ~(int64_t)3;
+    st.vec = vec_ok;
+    st.shift = vec_ok ? (int)(gblk - ablk) : 0;
+    st.base = params + gblk;
+    const uint64_t remain = (uint64_t)(n_param_floats - ablk) * 4u;
+#ifdef NF_KO_PARAM_LOADS        // timing-only build: an empty range drops every parameter fetch, the instruction stream stays
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(params + ablk), 0, remain > 0 ? 0u : 0u, 0x00020000);
+#else
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(params + ablk), 0,
+                                                remain > 0xffffffffull ? 0xffffffffu : (uint32_t)remain, 0x00020000);
+#endif
+    return st;
+}
+
+// pieces of the span that starts `rel` floats into the block (rel % 4 == 0) and holds nfl floats
+template <int MAXV>
+__device__ __forceinline__ void span_issue(const SpanStage& st, int rel, int nfl, int tid, float4 (&pre)[MAXV]) {
+    const int nvec = (st.shift + nfl + 3) >> 2;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = tid + i * kThreads;
+        const uint32_t off = v < nvec ? (uint32_t)(rel + 4 * v) * 4u : 0xfffffff0u;      // past the range: zeros, no fetch
+        pre[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(st.rsrc, off, 0, 0));
     }
-    return v;
+}
+
+template <int MAXV>
+__device__ __forceinline__ void span_commit(const SpanStage& st, int nfl, int tid, float* stage, const float4 (&pre)[MAXV]) {
+    const int nvec = (st.shift + nfl + 3) >> 2;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = tid + i * kThreads;
+        if (v < nvec) *reinterpret_cast<float4*>(stage + 4 * v) = pre[i];
+    }
+}
+
+__device__ __forceinline__ void span_scalar(const SpanStage& st, int rel, int nfl, int tid, float* stage) {
+    for (int f = tid; f < nfl; f += kThreads) stage[f] = st.base[rel + f];
 }
 
 // FAM: 0 rational-quadratic, 1 linear, 2 quadratic, 3 cubic spline (nf_spline_families.h); the staging is the same
@@ -69,57 +117,74 @@ __global__ __launch_bounds__(kThreads) void rqs_kernel(const RqsArgs a) {
     const int stage_floats = (kThreads * P + 4 + 3) & ~3;
     float* stage = smem;
     float* ldbuf = smem + stage_floats;
+    const int64_t e0 = row0 * D;                          // first element of the block
+    const SpanStage st = span_stage_init(a.params, a.n_param_floats, e0 * P, a.vec_ok);
+    // x / y rows back to back and no column index: element e of the block is float e0 + e of both (no division)
+    const bool flat = !a.feat && a.x_stride == D && a.y_stride == D;
+    const float inv_d = 1.0f / (float)D;
 
-    float4 pre[MAXV];
-    // span of iteration `it0`: floats [g0, g0 + n*P) of params; staged from the 4-float boundary below g0
-    auto issue = [&](int it0) {
-        const int n = min(kThreads, E - it0);
-        const int64_t g0 = (row0 * D + it0) * (int64_t)P;
-        const int64_t a0 = g0 & ~(int64_t)3;
-        const int nvec = (int)((g0 - a0 + (int64_t)n * P + 3) >> 2);
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = tid + i * kThreads;
-            pre[i] = v < nvec ? load_vec(a.params, a0 + 4 * (int64_t)v, a.n_param_floats, a.vec_ok)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    // Two spans of parameters are in flight (two register sets) while a third is evaluated: one block keeps up to
+    // 2 * 256 * P * 4 bytes outstanding, which is what it takes to keep HBM busy at 4 blocks per CU.
+    float4 preA[MAXV], preB[MAXV];
+    auto issue = [&](int it0, float4 (&pre)[MAXV]) {
+        if (st.vec && it0 < E) span_issue<MAXV>(st, it0 * P, min(kThreads, E - it0) * P, tid, pre);
     };
-    auto commit = [&](int it0) {
-        const int n = min(kThreads, E - it0);
-        const int64_t g0 = (row0 * D + it0) * (int64_t)P;
-        const int64_t a0 = g0 & ~(int64_t)3;
-        const int nvec = (int)((g0 - a0 + (int64_t)n * P + 3) >> 2);
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = tid + i * kThreads;
-            if (v < nvec) *reinterpret_cast<float4*>(stage + 4 * v) = pre[i];
-        }
-    };
-
-    if (E > 0) issue(0);
-    for (int it0 = 0; it0 < E; it0 += kThreads) {
-        __syncthreads();               // previous span fully consumed
-        commit(it0);
-        __syncthreads();
-        if (it0 + kThreads < E) issue(it0 + kThreads);   // in flight while this span is evaluated
-        const int n = min(kThreads, E - it0);
-        if (tid < n) {
-            const int e = it0 + tid;
-            const int r = e / D;
+    // element e of the block -> its offsets in x and y
+    auto locate = [&](int e, int64_t& xi, int64_t& yi) {
+        if (flat) {
+            xi = yi = e0 + e;
+        } else {
+            const int r = div_small(e, D, inv_d);
             const int d = e - r * D;
             const int col = a.feat ? a.feat[d] : d;
-            const int shift = (int)(((row0 * D + it0) * (int64_t)P) & 3);
-            const float xv = a.x[(row0 + r) * a.x_stride + col];
+            xi = (row0 + r) * a.x_stride + col;
+            yi = (row0 + r) * a.y_stride + col;
+        }
+    };
+    // x of the NEXT span is fetched one step ahead: a load issued after the parameter prefetch would have to wait for
+    // it (loads return in order), which is a full memory latency per step with nothing to hide it
+    float x_ahead = 0.0f;
+    {
+        int64_t xi, yi;
+        if (tid < E) { locate(tid, xi, yi); x_ahead = a.x[xi]; }
+    }
+    auto step = [&](int it0, float4 (&pre)[MAXV]) {
+        const int n = min(kThreads, E - it0);
+        __syncthreads();               // previous span fully consumed
+        if (st.vec) span_commit<MAXV>(st, n * P, tid, stage, pre);
+        else span_scalar(st, it0 * P, n * P, tid, stage);
+        __syncthreads();
+        const float xv = x_ahead;
+        if (it0 + kThreads + tid < E) {
+            int64_t xi, yi;
+            locate(it0 + kThreads + tid, xi, yi);
+            x_ahead = a.x[xi];
+        }
+        issue(it0 + 2 * kThreads, pre);                   // in flight while this span and the next are evaluated
+        if (tid < n) {
+            const int e = it0 + tid;
+            int64_t xi, yi;
+            locate(e, xi, yi);
+            typedef __attribute__((address_space(3))) float* lds_w;          // explicit LDS pointers: ds_ ops, never flat
+            typedef const __attribute__((address_space(3))) float* lds_r;
+            lds_w ps = (lds_w)(stage + st.shift + tid * P);
             float yv, ld;
             int bin;
-            if (FAM == 1) lin_eval<INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
-            else if (FAM == 2) quad_eval<INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
-            else if (FAM == 3) cubic_eval<INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
-            else rqs_eval<KT, INV>(stage + shift + tid * P, xv, a.c, yv, ld, bin);
-            a.y[(row0 + r) * a.y_stride + col] = yv;
-            if (a.bins) a.bins[(row0 + r) * (int64_t)D + d] = bin;
+            if (FAM == 1) lin_eval<INV, lds_w, true>(ps, xv, a.c, yv, ld, bin);
+            else if (FAM == 2) quad_eval<INV, lds_w, true>(ps, xv, a.c, yv, ld, bin);
+            else if (FAM == 3) cubic_eval<INV, lds_w, true>(ps, xv, a.c, yv, ld, bin);
+            else if (a.c.pre_div != 1.0f) rqs_eval<KT, INV, 1, false, false, lds_r>((lds_r)ps, xv, a.c, yv, ld, bin);
+            else rqs_eval<KT, INV, 1, false, false, lds_r, false>((lds_r)ps, xv, a.c, yv, ld, bin);
+            a.y[yi] = yv;
+            if (a.bins) a.bins[e0 + e] = bin;
             ldbuf[e] = ld;
         }
+    };
+    issue(0, preA);
+    issue(kThreads, preB);
+    for (int it0 = 0; it0 < E; it0 += 2 * kThreads) {
+        step(it0, preA);
+        if (it0 + kThreads < E) step(it0 + kThreads, preB);
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
@@ -155,7 +220,8 @@ struct RqsBwdArgs {
 };
 
 // FAM 0: rational-quadratic (gradients overwrite the staged parameters in place); 1 / 2 / 3: linear / quadratic /
-// cubic family (nf_spline_families.h), whose reverse sweeps keep the parameters and write a second LDS region
+// cubic family (nf_spline_families.h), whose reverse sweeps keep the parameters and write a second LDS region.
+// The next span's parameters are in flight (registers) while this one is evaluated and written back.
 template <int KT, int MAXV, int FAM = 0>
 __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -167,52 +233,80 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     const int E = nrows * D;
     float* stage = smem;
     float* gout = FAM ? smem + ((kThreads * P + 4 + 3) & ~3) : smem;
+    const int64_t e0 = row0 * D;
+    const int64_t gblk = e0 * P;
+    const SpanStage st = span_stage_init(a.params, a.n_param_floats, gblk, a.vec_ok);
+    const bool flat = a.x_stride == D && a.gy_stride == D && a.gx_stride == D;
+    const float inv_d = 1.0f / (float)D;
+    float* gbase = a.gparams + (gblk - st.shift);          // 16-byte aligned when st.vec
+
+    auto locate = [&](int e, int64_t& xi, int64_t& gyi, int64_t& gxi, int& r) {
+        r = div_small(e, D, inv_d);
+        if (flat) {
+            xi = gyi = gxi = e0 + e;
+        } else {
+            const int d = e - r * D;
+            xi = (row0 + r) * a.x_stride + d;
+            gyi = (row0 + r) * a.gy_stride + d;
+            gxi = (row0 + r) * a.gx_stride + d;
+        }
+    };
+    // per-element inputs of the NEXT span are fetched one step ahead (see rqs_kernel)
+    float x_ahead = 0.0f, gy_ahead = 0.0f, gl_ahead = 0.0f;
+    auto fetch_ahead = [&](int e) {
+        if (e < E) {
+            int64_t xi, gyi, gxi;
+            int r;
+            locate(e, xi, gyi, gxi, r);
+            x_ahead = a.x[xi];
+            gy_ahead = a.gy[gyi];
+            gl_ahead = a.glad[row0 + r];
+        }
+    };
+    fetch_ahead(tid);
+    float4 pre[MAXV];
+    if (st.vec && E > 0) span_issue<MAXV>(st, 0, min(kThreads, E) * P, tid, pre);
     for (int it0 = 0; it0 < E; it0 += kThreads) {
         const int n = min(kThreads, E - it0);
-        const int64_t g0 = (row0 * D + it0) * (int64_t)P;
-        const int64_t a0 = g0 & ~(int64_t)3;
-        const int shift = (int)(g0 - a0);
-        const int nvec = (int)((shift + (int64_t)n * P + 3) >> 2);
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = tid + i * kThreads;
-            if (v < nvec)
-                *reinterpret_cast<float4*>(stage + 4 * v) = load_vec(a.params, a0 + 4 * (int64_t)v, a.n_param_floats, a.vec_ok);
-        }
+        if (st.vec) span_commit<MAXV>(st, n * P, tid, stage, pre);
+        else span_scalar(st, it0 * P, n * P, tid, stage);
         __syncthreads();
+        const float xv = x_ahead, gyv = gy_ahead, gl = gl_ahead;
+        fetch_ahead(it0 + kThreads + tid);
+        if (st.vec && it0 + kThreads < E)
+            span_issue<MAXV>(st, (it0 + kThreads) * P, min(kThreads, E - it0 - kThreads) * P, tid, pre);
         if (tid < n) {
             const int e = it0 + tid;
-            const int r = e / D;
-            const int d = e - r * D;
-            const float xv = a.x[(row0 + r) * a.x_stride + d];
-            const float gyv = a.gy[(row0 + r) * a.gy_stride + d];
-            const float gl = a.glad[row0 + r];
-            float* ps = stage + shift + tid * P;
-            float* gs = gout + shift + tid * P;
+            int64_t xi, gyi, gxi;
+            int r;
+            locate(e, xi, gyi, gxi, r);
+            float* ps = stage + st.shift + tid * P;
+            float* gs = gout + st.shift + tid * P;
             float gxv;
             if (FAM == 1) gxv = lin_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
             else if (FAM == 2) gxv = quad_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
             else if (FAM == 3) gxv = cubic_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
             else gxv = rqs_bwd_eval<KT>(ps, xv, gyv, gl, a.c, a.inverse != 0);
-            a.gx[(row0 + r) * a.gx_stride + d] = gxv;
+            a.gx[gxi] = gxv;
         }
         __syncthreads();
-        // write the gradients of this span back: whole 16-byte vectors inside the span, scalars at its ends
-        const int64_t lo = g0, hi = g0 + (int64_t)n * P;
+        // write the gradients of this span back: floats [lo, hi) of the staged pieces are this span's; whole 16-byte
+        // pieces inside go out as such, the two pieces that straddle a neighbouring span float by float
+        const int lo = st.shift, hi = st.shift + n * P;
+        const int nvec = (hi + 3) >> 2;
+        float* gspan = gbase + (int64_t)it0 * P;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int v = tid + i * kThreads;
             if (v >= nvec) continue;
-            const int64_t f = a0 + 4 * (int64_t)v;
-            const float4 val = *reinterpret_cast<const float4*>(gout + 4 * v);
-            if (a.vec_ok && f >= lo && f + 3 < hi) {
-                *reinterpret_cast<float4*>(a.gparams + f) = val;
+            const int f = 4 * v;
+            if (st.vec && f >= lo && f + 3 < hi) {
+                *reinterpret_cast<float4*>(gspan + f) = *reinterpret_cast<const float4*>(gout + f);
             } else {
-                if (f >= lo && f < hi) a.gparams[f] = val.x;
-                if (f + 1 >= lo && f + 1 < hi) a.gparams[f + 1] = val.y;
-                if (f + 2 >= lo && f + 2 < hi) a.gparams[f + 2] = val.z;
-                if (f + 3 >= lo && f + 3 < hi) a.gparams[f + 3] = val.w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (f + q >= lo && f + q < hi) gspan[f + q] = gout[f + q];
             }
         }
     }

@@ -6,6 +6,10 @@
 #pragma once
 #include "nf_rqs_eval.h"
 
+// CACHE (forward evaluators): p is this lane's own writable copy of the parameters (the standalone kernel's LDS
+// stage), so exp(u - max) / the widths / exp(heights) are written over the logits once and re-read instead of being
+// recomputed by every loop below - same operations on the same values, so the same bits, at a third of the
+// transcendentals.  The backward evaluators always work this way.
 // torch.linspace(0, 1, K + 1)[i] in fp32: start + step * i in the lower half, end - step * (K - i) above
 __device__ __forceinline__ float nf_linspace01(int i, int K) {
     const float step = 1.0f / (float)K;
@@ -13,7 +17,7 @@ __device__ __forceinline__ float nf_linspace01(int i, int K) {
 }
 
 // Linear spline: p[0..K) = unnormalised pdf of K equal bins (linear.py:35-94; tails :9-33).
-template <bool INV, class PT = const float*>
+template <bool INV, class PT = const float*, bool CACHE = false>
 __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                          int& bin) {
     const int K = a.K;
@@ -28,7 +32,15 @@ __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float
     float m = -INFINITY;
     for (int k = 0; k < K; ++k) m = fmaxf(m, p[k]);
     float s = 0.0f;
-    for (int k = 0; k < K; ++k) s += nf_exp(p[k] - m);
+    for (int k = 0; k < K; ++k) {
+        const float e = nf_exp(p[k] - m);
+        if constexpr (CACHE) p[k] = e;
+        s += e;
+    }
+    auto ex = [&](int k) {
+        if constexpr (CACHE) return p[k];
+        else return nf_exp(p[k] - m);
+    };
     double acc = 0.0;
     float c0 = 0.0f;                       // cdf at the left edge of bin k
     if (!INV) {
@@ -38,7 +50,7 @@ __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float
         const float alpha = pos - (float)b;
         float pb = 0.0f, cb = 0.0f;
         for (int k = 0; k < K; ++k) {
-            const float pk = nf_exp(p[k] - m) / s;
+            const float pk = ex(k) / s;
             if (k == b) { pb = pk; cb = c0; }
             acc += (double)pk;
             c0 = (float)acc;
@@ -53,7 +65,7 @@ __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float
         float lo = 0.0f, hi = 0.0f;        // cdf at the two edges of the selected bin
         int b = 0;
         for (int k = 0; k < K; ++k) {
-            const float pk = nf_exp(p[k] - m) / s;
+            const float pk = ex(k) / s;
             acc += (double)pk;
             float c1 = (float)acc;
             if (k == K - 1) c1 = 1.0f + 1e-6f;      // pinned to 1, then raised in place by the search
@@ -75,7 +87,7 @@ __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float
 // Quadratic spline: p[0..K) unnormalised widths, p[K..P) unnormalised heights of the piecewise-linear density
 // (K+1 knots; with linear tails only the K-1 interior ones, the boundary pair set so that it normalises to 1)
 // (quadratic.py:48-135; tails :11-46).
-template <bool INV, class PT = const float*>
+template <bool INV, class PT = const float*, bool CACHE = false>
 __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                           int& bin) {
     const int K = a.K;
@@ -91,20 +103,36 @@ __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, floa
     float m = -INFINITY;
     for (int k = 0; k < K; ++k) m = fmaxf(m, uw[k]);
     float s = 0.0f;
-    for (int k = 0; k < K; ++k) s += nf_exp(uw[k] - m);
-    auto width = [&](int k) { return a.min_w + a.scale_w * (nf_exp(uw[k] - m) / s); };
+    for (int k = 0; k < K; ++k) {
+        const float e = nf_exp(uw[k] - m);
+        if constexpr (CACHE) uw[k] = e;
+        s += e;
+    }
+    if constexpr (CACHE) {
+        for (int k = 0; k < K; ++k) uw[k] = a.min_w + a.scale_w * (uw[k] / s);
+        const int nh = a.tails ? K - 1 : K + 1;
+        for (int j = 0; j < nh; ++j) uh[j] = nf_exp(uh[j]);
+    }
+    auto width = [&](int k) {
+        if constexpr (CACHE) return uw[k];
+        else return a.min_w + a.scale_w * (nf_exp(uw[k] - m) / s);
+    };
+    auto eh = [&](int j) {
+        if constexpr (CACHE) return uh[j];
+        else return nf_exp(uh[j]);
+    };
     // unnormalised knot heights H_0 .. H_K
     float cst = 0.0f;
     if (a.tails) {
         const float first = 0.5f * width(0), last = 0.5f * width(K - 1);
         float mid = 0.0f;
-        for (int j = 0; j + 1 < K - 1; ++j) mid += ((nf_exp(uh[j]) + nf_exp(uh[j + 1])) / 2.0f) * width(j + 1);
-        const float num = 0.5f * first * nf_exp(uh[0]) + 0.5f * last * nf_exp(uh[K - 2]) + mid;
+        for (int j = 0; j + 1 < K - 1; ++j) mid += ((eh(j) + eh(j + 1)) / 2.0f) * width(j + 1);
+        const float num = 0.5f * first * eh(0) + 0.5f * last * eh(K - 2) + mid;
         cst = num / (1.0f - 0.5f * first - 0.5f * last);
     }
     auto H = [&](int k) {
-        if (!a.tails) return nf_exp(uh[k]);
-        return (k == 0 || k == K) ? cst : nf_exp(uh[k - 1]);
+        if (!a.tails) return eh(k);
+        return (k == 0 || k == K) ? cst : eh(k - 1);
     };
     float area = 0.0f;
     for (int k = 0; k < K; ++k) area += ((H(k) + H(k + 1)) / 2.0f) * width(k);
@@ -155,7 +183,7 @@ __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, floa
 // p[2K], p[2K+1] unnormalised left / right boundary derivatives.  The interval is [a.left, a.right] in both
 // directions (the reference's default is [-10, 10]); a.pre_div divides the width / height logits (coupling).
 // eps and the near-quadratic threshold are the reference's defaults (1e-5, 1e-3).
-template <bool INV, class PT = const float*>
+template <bool INV, class PT = const float*, bool CACHE = false>
 __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                            int& bin) {
     const int K = a.K;
@@ -177,11 +205,25 @@ __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, flo
     }
     float sw = 0.0f, sh_ = 0.0f;
     for (int k = 0; k < K; ++k) {
-        sw += nf_exp(raw(uw, k) - mw);
-        sh_ += nf_exp(raw(uh, k) - mh);
+        const float ew = nf_exp(raw(uw, k) - mw), eh = nf_exp(raw(uh, k) - mh);
+        if constexpr (CACHE) { uw[k] = ew; uh[k] = eh; }
+        sw += ew;
+        sh_ += eh;
     }
-    auto width = [&](int k) { return a.min_w + a.scale_w * (nf_exp(raw(uw, k) - mw) / sw); };
-    auto height = [&](int k) { return a.min_h + a.scale_h * (nf_exp(raw(uh, k) - mh) / sh_); };
+    if constexpr (CACHE) {
+        for (int k = 0; k < K; ++k) {
+            uw[k] = a.min_w + a.scale_w * (uw[k] / sw);
+            uh[k] = a.min_h + a.scale_h * (uh[k] / sh_);
+        }
+    }
+    auto width = [&](int k) {
+        if constexpr (CACHE) return uw[k];
+        else return a.min_w + a.scale_w * (nf_exp(raw(uw, k) - mw) / sw);
+    };
+    auto height = [&](int k) {
+        if constexpr (CACHE) return uh[k];
+        else return a.min_h + a.scale_h * (nf_exp(raw(uh, k) - mh) / sh_);
+    };
     // bin search over the running sums
     double accw = 0.0, acch = 0.0;
     float cw0 = 0.0f, ch0 = 0.0f, lw = 0.0f, rw = 1.0f, d = 0.0f;
@@ -282,8 +324,7 @@ __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, flo
 // Everything below is in the normalised coordinates t = (x - left) / span, o = (y - left) / span.
 // ===================================================================================================================
 
-template <class PT>
-__device__ __forceinline__ float lin_bwd_eval(PT p, float* g, float x, float gy, float gl, const RqsConst& a, bool inv) {
+__device__ __forceinline__ float lin_bwd_eval(float* p, float* g, float x, float gy, float gl, const RqsConst& a, bool inv) {
     const int K = a.K;
     if (a.tails && !(x >= a.left && x <= a.right)) {
         for (int k = 0; k < K; ++k) g[k] = 0.0f;
@@ -293,14 +334,18 @@ __device__ __forceinline__ float lin_bwd_eval(PT p, float* g, float x, float gy,
     float m = -INFINITY;
     for (int k = 0; k < K; ++k) m = fmaxf(m, p[k]);
     float s = 0.0f;
-    for (int k = 0; k < K; ++k) s += nf_exp(p[k] - m);
+    for (int k = 0; k < K; ++k) {
+        const float e = nf_exp(p[k] - m);
+        p[k] = e;                                         // cached: the loops below re-read it
+        s += e;
+    }
     const float pos = t * (float)K;
     int b = (int)floorf(pos);
     b = b >= K ? K - 1 : (b < 0 ? 0 : b);
     const float alpha = pos - (float)b;
     float cb = 0.0f, pb = 0.0f;
     for (int k = 0; k <= b; ++k) {
-        const float pk = nf_exp(p[k] - m) / s;
+        const float pk = p[k] / s;
         if (k < b) cb += pk; else pb = pk;
     }
     const float o = cb + alpha * pb;
@@ -316,43 +361,54 @@ __device__ __forceinline__ float lin_bwd_eval(PT p, float* g, float x, float gy,
     const float go = gy * a.span;
     const float S = go * o + gl;                          // sum_k g_pdf[k] * pdf[k]
     for (int k = 0; k < K; ++k) {
-        const float pk = nf_exp(p[k] - m) / s;
+        const float pk = p[k] / s;
         const float gp = k < b ? go : (k == b ? go * alpha + gl / pb : 0.0f);
         g[k] = pk * (gp - S);
     }
     return inv ? A : gy * fp;
 }
 
-template <class PT>
-__device__ __forceinline__ float quad_bwd_eval(PT p, float* g, float x, float gy, float gl, const RqsConst& a, bool inv) {
+__device__ __forceinline__ float quad_bwd_eval(float* p, float* g, float x, float gy, float gl, const RqsConst& a, bool inv) {
     const int K = a.K, P = a.P;
     if (a.tails && !(x >= a.left && x <= a.right)) {
         for (int k = 0; k < P; ++k) g[k] = 0.0f;
         return gy;
     }
-    const PT uw = p;
-    const PT uh = p + K;
+    float* uw = p;
+    float* uh = p + K;
     float* gw = g;                 // [K]   dL/d width_k, then dL/d uw_k
     float* gE = g + K;             // [K-1] (tails) dL/d exp(uh_j)  |  [K+1] dL/d H_k
     const float t = (x - a.left) / a.span;
     float m = -INFINITY;
     for (int k = 0; k < K; ++k) m = fmaxf(m, uw[k]);
     float s = 0.0f;
-    for (int k = 0; k < K; ++k) s += nf_exp(uw[k] - m);
-    auto sm = [&](int k) { return nf_exp(uw[k] - m) / s; };
-    auto width = [&](int k) { return (k < 0 || k >= K) ? 0.0f : a.min_w + a.scale_w * sm(k); };
+    for (int k = 0; k < K; ++k) {
+        const float e = nf_exp(uw[k] - m);
+        uw[k] = e;
+        s += e;
+    }
+    // cached over the logits (p is this lane's own copy): the exact forward widths, and exp(uh)
+    for (int k = 0; k < K; ++k) uw[k] = a.min_w + a.scale_w * (uw[k] / s);
+    {
+        const int nh = a.tails ? K - 1 : K + 1;
+        for (int j = 0; j < nh; ++j) uh[j] = nf_exp(uh[j]);
+    }
+    const float isw = 1.0f / a.scale_w;
+    auto sm = [&](int k) { return (uw[k] - a.min_w) * isw; };
+    auto width = [&](int k) { return (k < 0 || k >= K) ? 0.0f : uw[k]; };
+    auto eh = [&](int j) { return uh[j]; };
     float cst = 0.0f, num = 0.0f, den = 1.0f;
     if (a.tails) {
         const float first = 0.5f * width(0), last = 0.5f * width(K - 1);
         float mid = 0.0f;
-        for (int j = 0; j + 1 < K - 1; ++j) mid += ((nf_exp(uh[j]) + nf_exp(uh[j + 1])) / 2.0f) * width(j + 1);
-        num = 0.5f * first * nf_exp(uh[0]) + 0.5f * last * nf_exp(uh[K - 2]) + mid;
+        for (int j = 0; j + 1 < K - 1; ++j) mid += ((eh(j) + eh(j + 1)) / 2.0f) * width(j + 1);
+        num = 0.5f * first * eh(0) + 0.5f * last * eh(K - 2) + mid;
         den = 1.0f - 0.5f * first - 0.5f * last;
         cst = num / den;
     }
     auto H = [&](int k) {
-        if (!a.tails) return nf_exp(uh[k]);
-        return (k == 0 || k == K) ? cst : nf_exp(uh[k - 1]);
+        if (!a.tails) return eh(k);
+        return (k == 0 || k == K) ? cst : eh(k - 1);
     };
     float area = 0.0f;
     for (int k = 0; k < K; ++k) area += ((H(k) + H(k + 1)) / 2.0f) * width(k);
@@ -423,7 +479,7 @@ __device__ __forceinline__ float quad_bwd_eval(PT p, float* g, float x, float gy
     if (a.tails) {
         const float gnum = gcst / den;
         const float gden = -gcst * num / (den * den);
-        const float E0 = nf_exp(uh[0]), EL = nf_exp(uh[K - 2]);
+        const float E0 = eh(0), EL = eh(K - 2);
         gw[0] += -0.25f * gden + 0.25f * E0 * gnum;
         gw[K - 1] += -0.25f * gden + 0.25f * EL * gnum;
         gE[0] += 0.25f * width(0) * gnum;
@@ -432,11 +488,11 @@ __device__ __forceinline__ float quad_bwd_eval(PT p, float* g, float x, float gy
             const float wj = width(j + 1);
             gE[j] += gnum * 0.5f * wj;
             gE[j + 1] += gnum * 0.5f * wj;
-            gw[j + 1] += gnum * 0.5f * (nf_exp(uh[j]) + nf_exp(uh[j + 1]));
+            gw[j + 1] += gnum * 0.5f * (eh(j) + eh(j + 1));
         }
-        for (int j = 0; j < K - 1; ++j) gE[j] *= nf_exp(uh[j]);
+        for (int j = 0; j < K - 1; ++j) gE[j] *= eh(j);
     } else {
-        for (int k = 0; k <= K; ++k) gE[k] *= nf_exp(uh[k]);
+        for (int k = 0; k <= K; ++k) gE[k] *= eh(k);
     }
     // softmax of the widths
     float S = 0.0f;
@@ -445,17 +501,16 @@ __device__ __forceinline__ float quad_bwd_eval(PT p, float* g, float x, float gy
     return inv ? A : gy * fp + gl * dldx;
 }
 
-template <class PT>
-__device__ __forceinline__ float cubic_bwd_eval(PT p, float* g, float x, float gy, float gl, const RqsConst& a, bool inv) {
+__device__ __forceinline__ float cubic_bwd_eval(float* p, float* g, float x, float gy, float gl, const RqsConst& a, bool inv) {
     const int K = a.K, P = a.P;
     if (a.tails && !(x >= a.left && x <= a.right)) {
         for (int k = 0; k < P; ++k) g[k] = 0.0f;
         return gy;
     }
-    const PT uw = p;
-    const PT uh = p + K;
+    float* uw = p;
+    float* uh = p + K;
     const bool scaled = a.pre_div != 1.0f;
-    auto raw = [&](PT u, int k) { return scaled ? u[k] / a.pre_div : u[k]; };
+    auto raw = [&](const float* u, int k) { return scaled ? u[k] / a.pre_div : u[k]; };
     const float t = (x - a.left) / a.span;
     float mw = -INFINITY, mh = -INFINITY;
     for (int k = 0; k < K; ++k) {
@@ -464,13 +519,21 @@ __device__ __forceinline__ float cubic_bwd_eval(PT p, float* g, float x, float g
     }
     float sw = 0.0f, sh_ = 0.0f;
     for (int k = 0; k < K; ++k) {
-        sw += nf_exp(raw(uw, k) - mw);
-        sh_ += nf_exp(raw(uh, k) - mh);
+        const float ew = nf_exp(raw(uw, k) - mw), eh = nf_exp(raw(uh, k) - mh);
+        uw[k] = ew;
+        uh[k] = eh;
+        sw += ew;
+        sh_ += eh;
     }
-    auto smw = [&](int k) { return nf_exp(raw(uw, k) - mw) / sw; };
-    auto smh = [&](int k) { return nf_exp(raw(uh, k) - mh) / sh_; };
-    auto width = [&](int k) { return a.min_w + a.scale_w * smw(k); };
-    auto height = [&](int k) { return a.min_h + a.scale_h * smh(k); };
+    for (int k = 0; k < K; ++k) {                         // cached over the logits: the exact forward widths / heights
+        uw[k] = a.min_w + a.scale_w * (uw[k] / sw);
+        uh[k] = a.min_h + a.scale_h * (uh[k] / sh_);
+    }
+    const float isw = 1.0f / a.scale_w, ish = 1.0f / a.scale_h;
+    auto smw = [&](int k) { return (uw[k] - a.min_w) * isw; };
+    auto smh = [&](int k) { return (uh[k] - a.min_h) * ish; };
+    auto width = [&](int k) { return uw[k]; };
+    auto height = [&](int k) { return uh[k]; };
     double accw = 0.0;
     float cw0 = 0.0f, lw = 0.0f;
     int b = 0;
