@@ -170,9 +170,9 @@ __global__ __launch_bounds__(kThreads) void rqs_kernel(const RqsArgs a) {
             lds_w ps = (lds_w)(stage + st.shift + tid * P);
             float yv, ld;
             int bin;
-            if (FAM == 1) lin_eval<INV, lds_w, true>(ps, xv, a.c, yv, ld, bin);
-            else if (FAM == 2) quad_eval<INV, lds_w, true>(ps, xv, a.c, yv, ld, bin);
-            else if (FAM == 3) cubic_eval<INV, lds_w, true>(ps, xv, a.c, yv, ld, bin);
+            if (FAM == 1) lin_eval<INV, lds_w, true, KT>(ps, xv, a.c, yv, ld, bin);
+            else if (FAM == 2) quad_eval<INV, lds_w, true, KT>(ps, xv, a.c, yv, ld, bin);
+            else if (FAM == 3) cubic_eval<INV, lds_w, true, KT>(ps, xv, a.c, yv, ld, bin);
             else if (a.c.pre_div != 1.0f) rqs_eval<KT, INV, 1, false, false, lds_r>((lds_r)ps, xv, a.c, yv, ld, bin);
             else rqs_eval<KT, INV, 1, false, false, lds_r, false>((lds_r)ps, xv, a.c, yv, ld, bin);
             a.y[yi] = yv;
@@ -501,7 +501,9 @@ template <bool INV, int FAM>
 int launch_family(const RqsArgs& a, int grid, size_t lds, hipStream_t s) {
     const int nv = (kThreads * a.c.P + 4 + 3) / 4;
     const int per = (nv + kThreads - 1) / kThreads;
-    if (per <= 6) hipLaunchKernelGGL((rqs_kernel<0, INV, 6, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
+    if (per <= 6 && a.c.K == 8) hipLaunchKernelGGL((rqs_kernel<8, INV, 6, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
+    else if (per <= 6 && a.c.K == 10) hipLaunchKernelGGL((rqs_kernel<10, INV, 6, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
+    else if (per <= 6) hipLaunchKernelGGL((rqs_kernel<0, INV, 6, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
     else if (per <= 12) hipLaunchKernelGGL((rqs_kernel<0, INV, 12, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
     else if (per <= 25) hipLaunchKernelGGL((rqs_kernel<0, INV, 25, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
     else return NF_ERR_SHAPE;

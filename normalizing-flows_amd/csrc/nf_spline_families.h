@@ -6,6 +6,7 @@
 #pragma once
 #include "nf_rqs_eval.h"
 
+// KT > 0: the bin count as a template constant.
 // CACHE (forward evaluators): p is this lane's own writable copy of the parameters (the standalone kernel's LDS
 // stage), so exp(u - max) / the widths / exp(heights) are written over the logits once and re-read instead of being
 // recomputed by every loop below - same operations on the same values, so the same bits, at a third of the
@@ -17,10 +18,10 @@ __device__ __forceinline__ float nf_linspace01(int i, int K) {
 }
 
 // Linear spline: p[0..K) = unnormalised pdf of K equal bins (linear.py:35-94; tails :9-33).
-template <bool INV, class PT = const float*, bool CACHE = false>
+template <bool INV, class PT = const float*, bool CACHE = false, int KT = 0>
 __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                          int& bin) {
-    const int K = a.K;
+    const int K = KT > 0 ? KT : a.K;          // KT: compile-time bin count (loops unroll, values stay in registers)
     if (a.tails && !(x >= a.left && x <= a.right)) {
         y = x;
         ld = 0.0f;
@@ -30,8 +31,10 @@ __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float
     const float t = (x - a.left) / a.span;
     const float lc = (float)log((double)a.span);
     float m = -INFINITY;
+#pragma unroll
     for (int k = 0; k < K; ++k) m = fmaxf(m, p[k]);
     float s = 0.0f;
+#pragma unroll
     for (int k = 0; k < K; ++k) {
         const float e = nf_exp(p[k] - m);
         if constexpr (CACHE) p[k] = e;
@@ -41,6 +44,7 @@ __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float
         if constexpr (CACHE) return p[k];
         else return nf_exp(p[k] - m);
     };
+    const NfDivisor ds = nf_divisor(s);
     double acc = 0.0;
     float c0 = 0.0f;                       // cdf at the left edge of bin k
     if (!INV) {
@@ -49,8 +53,9 @@ __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float
         b = b >= K ? K - 1 : b;
         const float alpha = pos - (float)b;
         float pb = 0.0f, cb = 0.0f;
+#pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float pk = ex(k) / s;
+            const float pk = nf_div_ieee(ex(k), ds);
             if (k == b) { pb = pk; cb = c0; }
             acc += (double)pk;
             c0 = (float)acc;
@@ -64,8 +69,9 @@ __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float
     } else {
         float lo = 0.0f, hi = 0.0f;        // cdf at the two edges of the selected bin
         int b = 0;
+#pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float pk = ex(k) / s;
+            const float pk = nf_div_ieee(ex(k), ds);
             acc += (double)pk;
             float c1 = (float)acc;
             if (k == K - 1) c1 = 1.0f + 1e-6f;      // pinned to 1, then raised in place by the search
@@ -87,10 +93,10 @@ __device__ __forceinline__ void lin_eval(PT p, float x, const RqsConst& a, float
 // Quadratic spline: p[0..K) unnormalised widths, p[K..P) unnormalised heights of the piecewise-linear density
 // (K+1 knots; with linear tails only the K-1 interior ones, the boundary pair set so that it normalises to 1)
 // (quadratic.py:48-135; tails :11-46).
-template <bool INV, class PT = const float*, bool CACHE = false>
+template <bool INV, class PT = const float*, bool CACHE = false, int KT = 0>
 __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                           int& bin) {
-    const int K = a.K;
+    const int K = KT > 0 ? KT : a.K;          // KT: compile-time bin count (loops unroll, values stay in registers)
     if (a.tails && !(x >= a.left && x <= a.right)) {
         y = x;
         ld = 0.0f;
@@ -101,21 +107,26 @@ __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, floa
     const PT uh = p + K;
     const float t = (x - a.left) / a.span;
     float m = -INFINITY;
+#pragma unroll
     for (int k = 0; k < K; ++k) m = fmaxf(m, uw[k]);
     float s = 0.0f;
+#pragma unroll
     for (int k = 0; k < K; ++k) {
         const float e = nf_exp(uw[k] - m);
         if constexpr (CACHE) uw[k] = e;
         s += e;
     }
+    const NfDivisor ds = nf_divisor(s);
     if constexpr (CACHE) {
-        for (int k = 0; k < K; ++k) uw[k] = a.min_w + a.scale_w * (uw[k] / s);
+#pragma unroll
+        for (int k = 0; k < K; ++k) uw[k] = a.min_w + a.scale_w * nf_div_ieee(uw[k], ds);
         const int nh = a.tails ? K - 1 : K + 1;
+#pragma unroll
         for (int j = 0; j < nh; ++j) uh[j] = nf_exp(uh[j]);
     }
     auto width = [&](int k) {
         if constexpr (CACHE) return uw[k];
-        else return a.min_w + a.scale_w * (nf_exp(uw[k] - m) / s);
+        else return a.min_w + a.scale_w * nf_div_ieee(nf_exp(uw[k] - m), ds);
     };
     auto eh = [&](int j) {
         if constexpr (CACHE) return uh[j];
@@ -126,6 +137,7 @@ __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, floa
     if (a.tails) {
         const float first = 0.5f * width(0), last = 0.5f * width(K - 1);
         float mid = 0.0f;
+#pragma unroll
         for (int j = 0; j + 1 < K - 1; ++j) mid += ((eh(j) + eh(j + 1)) / 2.0f) * width(j + 1);
         const float num = 0.5f * first * eh(0) + 0.5f * last * eh(K - 2) + mid;
         cst = num / (1.0f - 0.5f * first - 0.5f * last);
@@ -135,16 +147,19 @@ __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, floa
         return (k == 0 || k == K) ? cst : eh(k - 1);
     };
     float area = 0.0f;
+#pragma unroll
     for (int k = 0; k < K; ++k) area += ((H(k) + H(k + 1)) / 2.0f) * width(k);
     const float omh = 1.0f - a.min_h;
+    const NfDivisor da = nf_divisor(area);
     double accw = 0.0, accc = 0.0;
     float loc0 = 0.0f, cdf0 = 0.0f;                  // left edge of bin k: location and cdf
     float loc = 0.0f, w = 1.0f, c = 0.0f, hl = 1.0f, hr = 1.0f;
     int b = 0;
-    float hk = a.min_h + omh * (H(0) / area);
+    float hk = a.min_h + omh * nf_div_ieee(H(0), da);
+#pragma unroll
     for (int k = 0; k < K; ++k) {
         const float wk = width(k);
-        const float hk1 = a.min_h + omh * (H(k + 1) / area);
+        const float hk1 = a.min_h + omh * nf_div_ieee(H(k + 1), da);
         accw += (double)wk;
         accc += (double)(((hk + hk1) / 2.0f) * wk);
         float loc1 = (float)accw, cdf1 = (float)accc;
@@ -183,10 +198,10 @@ __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, floa
 // p[2K], p[2K+1] unnormalised left / right boundary derivatives.  The interval is [a.left, a.right] in both
 // directions (the reference's default is [-10, 10]); a.pre_div divides the width / height logits (coupling).
 // eps and the near-quadratic threshold are the reference's defaults (1e-5, 1e-3).
-template <bool INV, class PT = const float*, bool CACHE = false>
+template <bool INV, class PT = const float*, bool CACHE = false, int KT = 0>
 __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                            int& bin) {
-    const int K = a.K;
+    const int K = KT > 0 ? KT : a.K;          // KT: compile-time bin count (loops unroll, values stay in registers)
     if (a.tails && !(x >= a.left && x <= a.right)) {
         y = x;
         ld = 0.0f;
@@ -199,35 +214,40 @@ __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, flo
     auto raw = [&](PT u, int k) { return scaled ? u[k] / a.pre_div : u[k]; };
     const float t = (x - a.left) / a.span;
     float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
     for (int k = 0; k < K; ++k) {
         mw = fmaxf(mw, raw(uw, k));
         mh = fmaxf(mh, raw(uh, k));
     }
     float sw = 0.0f, sh_ = 0.0f;
+#pragma unroll
     for (int k = 0; k < K; ++k) {
         const float ew = nf_exp(raw(uw, k) - mw), eh = nf_exp(raw(uh, k) - mh);
         if constexpr (CACHE) { uw[k] = ew; uh[k] = eh; }
         sw += ew;
         sh_ += eh;
     }
+    const NfDivisor dw = nf_divisor(sw), dh = nf_divisor(sh_);
     if constexpr (CACHE) {
+#pragma unroll
         for (int k = 0; k < K; ++k) {
-            uw[k] = a.min_w + a.scale_w * (uw[k] / sw);
-            uh[k] = a.min_h + a.scale_h * (uh[k] / sh_);
+            uw[k] = a.min_w + a.scale_w * nf_div_ieee(uw[k], dw);
+            uh[k] = a.min_h + a.scale_h * nf_div_ieee(uh[k], dh);
         }
     }
     auto width = [&](int k) {
         if constexpr (CACHE) return uw[k];
-        else return a.min_w + a.scale_w * (nf_exp(raw(uw, k) - mw) / sw);
+        else return a.min_w + a.scale_w * nf_div_ieee(nf_exp(raw(uw, k) - mw), dw);
     };
     auto height = [&](int k) {
         if constexpr (CACHE) return uh[k];
-        else return a.min_h + a.scale_h * (nf_exp(raw(uh, k) - mh) / sh_);
+        else return a.min_h + a.scale_h * nf_div_ieee(nf_exp(raw(uh, k) - mh), dh);
     };
     // bin search over the running sums
     double accw = 0.0, acch = 0.0;
     float cw0 = 0.0f, ch0 = 0.0f, lw = 0.0f, rw = 1.0f, d = 0.0f;
     int b = 0;
+#pragma unroll
     for (int k = 0; k < K; ++k) {
         accw += (double)width(k);
         acch += (double)height(k);
