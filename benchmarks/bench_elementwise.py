@@ -70,6 +70,24 @@ def main():
     del p
     p = torch.randn(B, D * (2 * K + 2), device='cuda', generator=g)
     report('cubic_spline_fwd_K8', 2 * K + 2, lambda: _lib.cubic_spline(x, p, K, tails='linear', bound=10.0, out=y, logabsdet=ld))
+    del p
+
+    # backward kernels: parameters read + their gradients written + x, grad_y read + grad_x written + grad_logabsdet
+    def report_bwd(name, P, fn):
+        ms = timed(fn, args.reps)
+        byts = B * (D * (8 * P + 12) + 4)
+        gbs = byts / (ms * 1e-3) / 1e9
+        out['kernels'][name] = {'params_per_element': P, 'algorithmic_bytes': byts, 'ms': round(ms, 4),
+                                'achieved_gbs': round(gbs, 1), 'frac': round(gbs / PEAK_GBS, 3)}
+
+    gy = torch.randn(B, D, device='cuda', generator=g)
+    gl = torch.randn(B, device='cuda', generator=g)
+    p = torch.randn(B, D * (3 * K - 1), device='cuda', generator=g)
+    report_bwd('rqs_bwd_K8_linear_tails', 3 * K - 1, lambda: _lib.rqs_bwd(x, p, gy, gl, K, 'linear', T))
+    del p
+    p = torch.randn(B, D * (2 * K + 2), device='cuda', generator=g)
+    report_bwd('cubic_spline_bwd_K8', 2 * K + 2, lambda: _lib.family_spline_bwd('cubic', x, p, gy, gl, K, tails='linear',
+                                                                                tail_bound=10.0))
     print(json.dumps(out))
 
 

@@ -170,9 +170,26 @@ __global__ __launch_bounds__(kThreads) void rqs_kernel(const RqsArgs a) {
             lds_w ps = (lds_w)(stage + st.shift + tid * P);
             float yv, ld;
             int bin;
-            if (FAM == 1) lin_eval<INV, lds_w, true, KT>(ps, xv, a.c, yv, ld, bin);
+            if constexpr (FAM == 1 && KT > 0) {
+                // compile-time K: the element's K logits move to registers once (every index in lin_eval is static
+                // after unrolling), so its cached values never go back to LDS (P = 8: a 16-way bank conflict per access)
+                float pv[KT];
+                if (KT % 4 == 0 && st.shift == 0) {                   // P = K floats per lane, 16-byte aligned
+#pragma unroll
+                    for (int q = 0; q < KT / 4; ++q) {
+                        typedef float f4 __attribute__((ext_vector_type(4)));
+                        const f4 v4 = *reinterpret_cast<const __attribute__((address_space(3))) f4*>(ps + 4 * q);
+                        pv[4 * q] = v4[0]; pv[4 * q + 1] = v4[1]; pv[4 * q + 2] = v4[2]; pv[4 * q + 3] = v4[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < KT; ++q) pv[q] = ps[q];
+                }
+                lin_eval<INV, float*, true, KT>(pv, xv, a.c, yv, ld, bin);
+            } else if (FAM == 1) lin_eval<INV, lds_w, true, KT>(ps, xv, a.c, yv, ld, bin);
             else if (FAM == 2) quad_eval<INV, lds_w, true, KT>(ps, xv, a.c, yv, ld, bin);
-            else if (FAM == 3) cubic_eval<INV, lds_w, true, KT>(ps, xv, a.c, yv, ld, bin);
+            else if (FAM == 3 && a.c.pre_div != 1.0f) cubic_eval<INV, lds_w, true, KT, 1>(ps, xv, a.c, yv, ld, bin);
+            else if (FAM == 3) cubic_eval<INV, lds_w, true, KT, 0>(ps, xv, a.c, yv, ld, bin);
             else if (a.c.pre_div != 1.0f) rqs_eval<KT, INV, 1, false, false, lds_r>((lds_r)ps, xv, a.c, yv, ld, bin);
             else rqs_eval<KT, INV, 1, false, false, lds_r, false>((lds_r)ps, xv, a.c, yv, ld, bin);
             a.y[yi] = yv;
@@ -365,25 +382,41 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(const AffineArgs a) {
     const int64_t row0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int nrows = (int)min((int64_t)a.rows_per_block, a.B - row0);
     const int E = nrows * D;
+    const float inv_d = 1.0f / (float)D;
+    // rows back to back, interleaved parameters, no column index: element e of the block is float e0 + e of x and y
+    // and float2 e0 + e of the parameters - no division, every access a straight stream
+    const bool flat = !a.feat && a.x_stride == D && a.y_stride == D && a.layout == NF_AFFINE_INTERLEAVED &&
+                      a.p_stride == 2 * (int64_t)D;
+    const int64_t e0 = row0 * D;
     for (int e = tid; e < E; e += kThreads) {
-        const int r = e / D;
-        const int d = e - r * D;
-        const int col = a.feat ? a.feat[d] : d;
-        const float* prow = a.params + (row0 + r) * a.p_stride;
         float us, shift;
-        if (a.layout == NF_AFFINE_INTERLEAVED) {
-            const float2 v = *reinterpret_cast<const float2*>(prow + 2 * d);
+        int64_t xi, yi;
+        if (flat) {
+            const float2 v = reinterpret_cast<const float2*>(a.params)[e0 + e];
             us = v.x;
             shift = v.y;
+            xi = yi = e0 + e;
         } else {
-            shift = prow[d];
-            us = prow[D + d];
+            const int r = div_small(e, D, inv_d);
+            const int d = e - r * D;
+            const int col = a.feat ? a.feat[d] : d;
+            const float* prow = a.params + (row0 + r) * a.p_stride;
+            if (a.layout == NF_AFFINE_INTERLEAVED) {
+                const float2 v = *reinterpret_cast<const float2*>(prow + 2 * d);
+                us = v.x;
+                shift = v.y;
+            } else {
+                shift = prow[d];
+                us = prow[D + d];
+            }
+            xi = (row0 + r) * a.x_stride + col;
+            yi = (row0 + r) * a.y_stride + col;
         }
         const float z = us + 2.0f;
         const float scale = 1.0f / (1.0f + expf(-z)) + 1e-3f;       // sigmoid(u + 2) + 1e-3
         const float ls = logf(scale);
-        const float xv = a.x[(row0 + r) * a.x_stride + col];
-        a.y[(row0 + r) * a.y_stride + col] = INV ? (xv - shift) / scale : scale * xv + shift;
+        const float xv = a.x[xi];
+        a.y[yi] = INV ? (xv - shift) / scale : scale * xv + shift;
         smem[e] = INV ? -ls : ls;
     }
     __syncthreads();

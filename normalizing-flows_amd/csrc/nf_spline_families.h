@@ -198,7 +198,7 @@ __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, floa
 // p[2K], p[2K+1] unnormalised left / right boundary derivatives.  The interval is [a.left, a.right] in both
 // directions (the reference's default is [-10, 10]); a.pre_div divides the width / height logits (coupling).
 // eps and the near-quadratic threshold are the reference's defaults (1e-5, 1e-3).
-template <bool INV, class PT = const float*, bool CACHE = false, int KT = 0>
+template <bool INV, class PT = const float*, bool CACHE = false, int KT = 0, int PREDIV = -1>
 __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, float& y, float& ld,
                                            int& bin) {
     const int K = KT > 0 ? KT : a.K;          // KT: compile-time bin count (loops unroll, values stay in registers)
@@ -210,8 +210,19 @@ __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, flo
     }
     const PT uw = p;
     const PT uh = p + K;
-    const bool scaled = a.pre_div != 1.0f;
-    auto raw = [&](PT u, int k) { return scaled ? u[k] / a.pre_div : u[k]; };
+    // PREDIV: 1 / 0 = the caller has branched on pre_div != 1 (no per-logit select), -1 = decide here
+    const bool scaled = PREDIV < 0 ? a.pre_div != 1.0f : PREDIV != 0;
+    const NfDivisor dpre = nf_divisor(a.pre_div);
+    if constexpr (CACHE && PREDIV != 0) {                 // divide once, in place
+        if (scaled) {
+#pragma unroll
+            for (int k = 0; k < 2 * K; ++k) uw[k] = nf_div_ieee(uw[k], dpre);
+        }
+    }
+    auto raw = [&](PT u, int k) {
+        if constexpr (CACHE || PREDIV == 0) return u[k];
+        else return scaled ? nf_div_ieee(u[k], dpre) : u[k];
+    };
     const float t = (x - a.left) / a.span;
     float mw = -INFINITY, mh = -INFINITY;
 #pragma unroll
