@@ -109,27 +109,39 @@ __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, floa
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < K; ++k) m = fmaxf(m, uw[k]);
+    // KT > 0: widths and exp(heights) live in registers (every index below is static once the loops unroll);
+    // otherwise CACHE keeps them over the logits in LDS
+    constexpr int KA = KT > 0 ? KT : 1;
+    float wv[KA], ev[KA + 1];
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const float e = nf_exp(uw[k] - m);
-        if constexpr (CACHE) uw[k] = e;
+        if constexpr (KT > 0) wv[k] = e;
+        else if constexpr (CACHE) uw[k] = e;
         s += e;
     }
     const NfDivisor ds = nf_divisor(s);
-    if constexpr (CACHE) {
+    const int nh = a.tails ? K - 1 : K + 1;
+    if constexpr (KT > 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) wv[k] = a.min_w + a.scale_w * nf_div_ieee(wv[k], ds);
+#pragma unroll
+        for (int j = 0; j < K + 1; ++j) ev[j] = j < K - 1 || j < nh ? nf_exp(uh[j]) : 0.0f;
+    } else if constexpr (CACHE) {
 #pragma unroll
         for (int k = 0; k < K; ++k) uw[k] = a.min_w + a.scale_w * nf_div_ieee(uw[k], ds);
-        const int nh = a.tails ? K - 1 : K + 1;
 #pragma unroll
         for (int j = 0; j < nh; ++j) uh[j] = nf_exp(uh[j]);
     }
     auto width = [&](int k) {
-        if constexpr (CACHE) return uw[k];
+        if constexpr (KT > 0) return wv[k];
+        else if constexpr (CACHE) return uw[k];
         else return a.min_w + a.scale_w * nf_div_ieee(nf_exp(uw[k] - m), ds);
     };
     auto eh = [&](int j) {
-        if constexpr (CACHE) return uh[j];
+        if constexpr (KT > 0) return ev[j];
+        else if constexpr (CACHE) return uh[j];
         else return nf_exp(uh[j]);
     };
     // unnormalised knot heights H_0 .. H_K
@@ -142,9 +154,17 @@ __device__ __forceinline__ void quad_eval(PT p, float x, const RqsConst& a, floa
         const float num = 0.5f * first * eh(0) + 0.5f * last * eh(K - 2) + mid;
         cst = num / (1.0f - 0.5f * first - 0.5f * last);
     }
+    float hv[KA + 1];                                // KT > 0: the K + 1 knot heights, resolved once
+    if constexpr (KT > 0) {
+#pragma unroll
+        for (int k = 0; k <= K; ++k) hv[k] = !a.tails ? ev[k] : ((k == 0 || k == K) ? cst : ev[k - 1]);
+    }
     auto H = [&](int k) {
-        if (!a.tails) return eh(k);
-        return (k == 0 || k == K) ? cst : eh(k - 1);
+        if constexpr (KT > 0) return hv[k];
+        else {
+            if (!a.tails) return eh(k);
+            return (k == 0 || k == K) ? cst : eh(k - 1);
+        }
     };
     float area = 0.0f;
 #pragma unroll
