@@ -379,6 +379,18 @@ int nf_rqs_bwd(const float* x, int64_t x_row_stride, const float* params, int64_
                int tails, double tail_bound, double min_bin_width, double min_bin_height,
                double min_derivative, void* stream);
 
+/* nf_rqs_bwd / nf_rqs_inverse_bwd (inverse = 0 / 1) that also leaves, in *grad_params_max, the bit pattern of the
+ * largest finite |grad_params| element (the slot is zeroed on the stream first): the fp16 operand scale that the f16x2
+ * GEMMs of the conditioner's backward (nf_masked_linear_split_fwd on the transposed layer, nf_masked_linear_split_bwd_weight)
+ * take, so that no separate nf_maxabs pass over the [B, D*P] gradient is needed.  No counterpart in the reference
+ * (autograd keeps fp32 throughout). */
+int nf_rqs_bwd_max(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                   double pre_div, const float* grad_y, int64_t grad_y_row_stride,
+                   const float* grad_logabsdet, float* grad_x, int64_t grad_x_row_stride, float* grad_params,
+                   uint32_t* grad_params_max, int64_t B, int D, int K, int tails, double tail_bound,
+                   double min_bin_width, double min_bin_height, double min_derivative, int inverse,
+                   void* stream);
+
 /* Backward of nf_rqs_fwd(inverse = 1, feat_index = NULL) - the sampling direction the reference's default reverse-KL
  * loss differentiates (model.py:135-139 through :78-85): x_out is that pass's OUTPUT (nothing else is saved), and by
  * implicit differentiation of y_in = f(x_out; params) the kernel turns grad_x_out [B,D] and grad_logabsdet [B] into

@@ -153,6 +153,10 @@ _SIGNATURES = {
     'nf_rqs_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p, _c.c_int64,
                               _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
                               _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_void_p]),
+    'nf_rqs_bwd_max': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p, _c.c_int64,
+                                  _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int,
+                                  _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
+                                  _c.c_void_p]),
     'nf_rqs_inverse_bwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p,
                                       _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int,
                                       _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double,
@@ -435,7 +439,7 @@ def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=Tru
 
 
 def rqs_bwd(x, params, grad_y, grad_lad, num_bins, tails, tail_bound, pre_div=1.0, min_bin_width=1e-3,
-            min_bin_height=1e-3, min_derivative=1e-3, inverse=False):
+            min_bin_height=1e-3, min_derivative=1e-3, inverse=False, want_max=False):
     """(grad wrt the spline's input, grad_params).  inverse: backward of the inverse direction - `x` is then that
     pass's OUTPUT and grad_y the gradient wrt it (nf_rqs_inverse_bwd)."""
     lib = load()
@@ -450,6 +454,17 @@ def rqs_bwd(x, params, grad_y, grad_lad, num_bins, tails, tail_bound, pre_div=1.
     gparams = torch.empty_like(params)
     gl = grad_lad.contiguous()
     with torch.cuda.device(x.device):
+        if want_max:
+            # the kernel leaves max |grad_params| in a slot and the gradient carries it as a tag: the f16x2 GEMMs of
+            # the conditioner's backward then skip their own pass over this (large) tensor
+            slot = torch.empty(1, dtype=torch.int32, device=x.device)
+            _check(lib.nf_rqs_bwd_max(xp, xs, pp, ps, float(pre_div), gyp, gys, gl.data_ptr(), gxp, gxs,
+                                      gparams.data_ptr(), slot.data_ptr(), B, D, int(num_bins),
+                                      1 if tails == 'linear' else 0, float(tail_bound), float(min_bin_width),
+                                      float(min_bin_height), float(min_derivative), int(inverse), _stream()),
+                   'nf_rqs_bwd_max')
+            tag_max(gparams, slot)
+            return gx, gparams
         fn = lib.nf_rqs_inverse_bwd if inverse else lib.nf_rqs_bwd
         _check(fn(xp, xs, pp, ps, float(pre_div), gyp, gys, gl.data_ptr(), gxp, gxs, gparams.data_ptr(), B,
                   D, int(num_bins), 1 if tails == 'linear' else 0, float(tail_bound),

@@ -60,7 +60,11 @@ class MaskedLinearFn(torch.autograd.Function):
         grad_y = grad_y.contiguous()
         gx = gw = gb = None
         split_y = _split_mode(grad_y, layer.out_features)
-        gy_max = _lib.maxabs(grad_y) if split_y else None
+        gy_max = None
+        if split_y:
+            gy_max = _lib.tagged_max(grad_y)               # left by the kernel that produced it (nf_rqs_bwd_max)
+            if gy_max is None:
+                gy_max = _lib.maxabs(grad_y)
         if ctx.needs_input_grad[0]:
             if split_y:
                 # dX = dY @ (W * mask): the same split-operand kernel on the transposed layer, ReLU gate in its epilogue
@@ -105,7 +109,7 @@ class RqsFn(torch.autograd.Function):
             grad_lad = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
         gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
                                    pre_div=pre_div, min_bin_width=mins[0], min_bin_height=mins[1],
-                                   min_derivative=mins[2], inverse=inverse)
+                                   min_derivative=mins[2], inverse=inverse, want_max=_f16x2_mode())
         return gx, gparams, None, None, None, None, None, None
 
 

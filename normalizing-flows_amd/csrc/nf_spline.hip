@@ -234,6 +234,7 @@ struct RqsBwdArgs {
     int rows_per_block;
     int vec_ok;                // params AND gparams 16-byte aligned
     int inverse;               // backward of the inverse direction (x = the inverse pass's OUTPUT, see rqs_bwd_eval)
+    unsigned* gmax;            // nullable: atomicMax of the bit pattern of the largest finite |grad_params| written
 };
 
 // FAM 0: rational-quadratic (gradients overwrite the staged parameters in place); 1 / 2 / 3: linear / quadratic /
@@ -281,6 +282,11 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
         }
     };
     fetch_ahead(tid);
+    float gm = 0.0f;                                       // largest finite |gradient| this lane wrote
+    auto seen = [&](float v) {
+        const float av = fabsf(v);
+        gm = fmaxf(gm, av < INFINITY ? av : 0.0f);
+    };
     float4 pre[MAXV];
     if (st.vec && E > 0) span_issue<MAXV>(st, 0, min(kThreads, E) * P, tid, pre);
     for (int it0 = 0; it0 < E; it0 += kThreads) {
@@ -319,12 +325,25 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
             if (v >= nvec) continue;
             const int f = 4 * v;
             if (st.vec && f >= lo && f + 3 < hi) {
-                *reinterpret_cast<float4*>(gspan + f) = *reinterpret_cast<const float4*>(gout + f);
+                const float4 gv = *reinterpret_cast<const float4*>(gout + f);
+                *reinterpret_cast<float4*>(gspan + f) = gv;
+                seen(gv.x); seen(gv.y); seen(gv.z); seen(gv.w);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (f + q >= lo && f + q < hi) gspan[f + q] = gout[f + q];
+                    if (f + q >= lo && f + q < hi) { gspan[f + q] = gout[f + q]; seen(gout[f + q]); }
             }
+        }
+    }
+    if (a.gmax) {                                          // one atomic per workgroup (uniform branch)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gm = fmaxf(gm, __shfl_xor(gm, off, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) smem[tid >> 6] = gm;
+        __syncthreads();
+        if (tid == 0) {
+            gm = fmaxf(fmaxf(smem[0], smem[1]), fmaxf(smem[2], smem[3]));
+            if (gm > 0.0f) atomicMax(a.gmax, __float_as_uint(gm));
         }
     }
 }
@@ -737,9 +756,13 @@ static int rqs_bwd_impl(const float* x, int64_t x_row_stride, const float* param
                         double pre_div, const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
                         float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D, int K,
                         int tails, double tail_bound, double min_bin_width, double min_bin_height,
-                        double min_derivative, int inverse, void* stream) {
+                        double min_derivative, int inverse, void* stream, uint32_t* grad_params_max = nullptr) {
     if (B < 0 || D <= 0 || K <= 0 || K > 32) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
+    if (grad_params_max) {                                 // the slot starts at 0 even for an empty batch
+        const hipError_t me = hipMemsetAsync(grad_params_max, 0, sizeof(uint32_t), (hipStream_t)stream);
+        if (me != hipSuccess) return (int)me;
+    }
     if (B == 0) return NF_OK;
     if (!x || !params || !grad_y || !grad_logabsdet || !grad_x || !grad_params) return NF_ERR_NULL;
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
@@ -753,6 +776,7 @@ static int rqs_bwd_impl(const float* x, int64_t x_row_stride, const float* param
     a.rows_per_block = pick_rows_per_block(D, B);
     a.vec_ok = (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0;
     a.inverse = inverse;
+    a.gmax = grad_params_max;
     const size_t lds = sizeof(float) * (size_t)((kThreads * P + 4 + 3) & ~3);
     const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
@@ -801,6 +825,7 @@ static int family_bwd(const float* x, int64_t x_row_stride, const float* params,
     a.rows_per_block = pick_rows_per_block(D, B);
     a.vec_ok = (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0;
     a.inverse = inverse;
+    a.gmax = nullptr;
     const size_t lds = 2 * sizeof(float) * (size_t)((kThreads * P + 4 + 3) & ~3);     // parameters + gradients
     if (lds > 160 * 1024) return NF_ERR_SHAPE;
     const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
@@ -839,6 +864,21 @@ extern "C" int nf_cubic_spline_bwd(const float* x, int64_t x_row_stride, const f
     return family_bwd<3>(x, x_row_stride, params, param_row_stride, grad_y, grad_y_row_stride, grad_logabsdet, grad_x,
                          grad_x_row_stride, grad_params, B, D, K, 2 * K + 2, tails, bound, min_bin_width,
                          min_bin_height, inverse, stream, pre_div, true);
+}
+
+// nf_rqs_bwd that also leaves the bit pattern of the largest finite |grad_params| in *grad_params_max (zeroed here,
+// then atomicMax per workgroup): the operand scale the f16x2 GEMMs of the conditioner's backward need, without the
+// extra pass over the [B, D*P] gradient that finding it afterwards costs.
+extern "C" int nf_rqs_bwd_max(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                              double pre_div, const float* grad_y, int64_t grad_y_row_stride,
+                              const float* grad_logabsdet, float* grad_x, int64_t grad_x_row_stride, float* grad_params,
+                              uint32_t* grad_params_max, int64_t B, int D, int K, int tails, double tail_bound,
+                              double min_bin_width, double min_bin_height, double min_derivative, int inverse,
+                              void* stream) {
+    if (!grad_params_max) return NF_ERR_NULL;
+    return rqs_bwd_impl(x, x_row_stride, params, param_row_stride, pre_div, grad_y, grad_y_row_stride, grad_logabsdet,
+                        grad_x, grad_x_row_stride, grad_params, B, D, K, tails, tail_bound, min_bin_width,
+                        min_bin_height, min_derivative, inverse ? 1 : 0, stream, grad_params_max);
 }
 
 // Backward of nf_rqs_fwd(inverse = 1): x_out = the inverse pass's OUTPUT, grad_x_out / grad_logabsdet the gradients

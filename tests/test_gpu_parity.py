@@ -2140,3 +2140,28 @@ def test_spline_family_transforms_train(nf, family, direction):
             assert _nerr(named[k].grad.cpu(), v.grad) < 2e-3, (k, _nerr(named[k].grad.cpu(), v.grad))
             checked += 1
     assert checked >= 4
+
+
+def test_rqs_bwd_leaves_the_gradient_scale(nf):
+    """nf_rqs_bwd_max: the slot holds exactly max |grad_params| (what nf_maxabs finds in a separate pass), the
+    gradients are those of nf_rqs_bwd, and the tag survives into the consumer only while the tensor is unchanged."""
+    g = torch.Generator(device='cuda').manual_seed(8)
+    B, D, K = 300, 13, 8
+    x = torch.randn(B, D, device='cuda', generator=g) * 2
+    p = torch.randn(B, D * 23, device='cuda', generator=g)
+    gy, gl = torch.randn(B, D, device='cuda', generator=g), torch.randn(B, device='cuda', generator=g)
+    for inverse in (False, True):
+        gx0, gp0 = nf._lib.rqs_bwd(x, p, gy, gl, K, 'linear', 3.0, inverse=inverse)
+        gx1, gp1 = nf._lib.rqs_bwd(x, p, gy, gl, K, 'linear', 3.0, inverse=inverse, want_max=True)
+        assert torch.equal(gx0, gx1) and torch.equal(gp0, gp1)
+        slot = nf._lib.tagged_max(gp1)
+        assert slot is not None and nf._lib.tagged_max(gp0) is None
+        fin = gp1[torch.isfinite(gp1)]
+        assert slot.view(torch.float32).item() == fin.abs().max().item()
+        assert torch.equal(slot, nf._lib.maxabs(gp1))
+        gp1.mul_(2.0)
+        assert nf._lib.tagged_max(gp1) is None              # written since: the tag is stale
+    e = torch.empty(0, D, device='cuda')
+    _, gpe = nf._lib.rqs_bwd(e, torch.empty(0, D * 23, device='cuda'), e, torch.empty(0, device='cuda'), K, 'linear',
+                             3.0, want_max=True)
+    assert nf._lib.tagged_max(gpe).item() == 0
