@@ -362,6 +362,14 @@ int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, cons
                                       const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
                                       const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,
                                       int64_t B, int in, int out, int relu_in, void* stream);
+
+/* The same weight gradient with ONE scaled fp16 term per operand (11 significant bits relative to each tensor's largest
+ * element, fp32 accumulation, a third of the MFMAs): what the bf16 training mode uses (BASELINE config 5 "bf16 MADE
+ * MFMA backward"; 2e-2 tolerance class).  Same arguments. */
+int nf_masked_linear_half_bwd_weight(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                     const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
+                                     const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,
+                                     int64_t B, int in, int out, int relu_in, void* stream);
 /* Backward of nf_affine_fwd (either direction; replaces autograd through transforms.py:540-566 / :323-347): from x,
  * params (scale recomputed), grad_y[B, x columns] and grad_logabsdet[B] (nullable = 0) to grad_x (written at the D
  * transformed columns only; with feat_index the caller owns the identity columns) and grad_params[B, 2D] in the

@@ -107,6 +107,9 @@ _SIGNATURES = {
     'nf_masked_linear_split_bwd_weight': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                                       _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                       _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_masked_linear_half_bwd_weight': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_maxabs': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p]),
     'nf_masked_linear_split_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                               _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
@@ -414,9 +417,11 @@ def masked_linear_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True):
     return gw, gb
 
 
-def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True, x_max=None, grad_y_max=None):
-    """masked_linear_bwd_weight on two-term fp16 operands (the f16x2 training mode); the max slots are computed
-    here when the caller has none."""
+def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True, x_max=None, grad_y_max=None,
+                                   terms=2):
+    """masked_linear_bwd_weight on two-term fp16 operands (the f16x2 training mode) or, terms=1, on one scaled fp16
+    term (the bf16 training mode: nf_masked_linear_half_bwd_weight); the max slots are computed here when the caller
+    has none."""
     lib = load()
     _dev(x, 'x')
     _dev(grad_y, 'grad_y')
@@ -432,9 +437,10 @@ def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=Tru
     gb = torch.zeros(out, dtype=torch.float32, device=x.device) if want_bias else None
     m = None if mask is None else _dev(mask.contiguous(), 'mask')
     with torch.cuda.device(x.device):
-        _check(lib.nf_masked_linear_split_bwd_weight(xp, xs, x_max.data_ptr(), gp, gs, grad_y_max.data_ptr(), _ptr(m),
-                                                     _ptr(ktab), gw.data_ptr(), _ptr(gb), B, inp, out, int(relu_in),
-                                                     _stream()), 'nf_masked_linear_split_bwd_weight')
+        fn = lib.nf_masked_linear_split_bwd_weight if terms == 2 else lib.nf_masked_linear_half_bwd_weight
+        _check(fn(xp, xs, x_max.data_ptr(), gp, gs, grad_y_max.data_ptr(), _ptr(m), _ptr(ktab), gw.data_ptr(), _ptr(gb),
+                  B, inp, out, int(relu_in), _stream()),
+               'nf_masked_linear_split_bwd_weight' if terms == 2 else 'nf_masked_linear_half_bwd_weight')
     return gw, gb
 
 

@@ -60,11 +60,9 @@ class MaskedLinearFn(torch.autograd.Function):
         grad_y = grad_y.contiguous()
         gx = gw = gb = None
         split_y = _split_mode(grad_y, layer.out_features)
-        gy_max = None
-        if split_y:
-            gy_max = _lib.tagged_max(grad_y)               # left by the kernel that produced it (nf_rqs_bwd_max)
-            if gy_max is None:
-                gy_max = _lib.maxabs(grad_y)
+        gy_max = _lib.tagged_max(grad_y)                   # left by the kernel that produced it (nf_rqs_bwd_max)
+        if split_y and gy_max is None:
+            gy_max = _lib.maxabs(grad_y)
         if ctx.needs_input_grad[0]:
             if split_y:
                 # dX = dY @ (W * mask): the same split-operand kernel on the transposed layer, ReLU gate in its epilogue
@@ -74,10 +72,10 @@ class MaskedLinearFn(torch.autograd.Function):
                 gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if ctx.relu_in else None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if _bf16_mode() and _lib.split_gemm_supported(grad_y, layer.out_features):
-                # bf16 mode has no bf16 weight-gradient kernel: the two-term fp16 one (more exact, fp16 MFMA rate)
+                # bf16 mode: one scaled fp16 term per operand (11 bits against bf16's 8, same MFMA rate)
                 gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
                                                              layer._packed_linear().ktab, ctx.relu_in,
-                                                             want_bias=ctx.has_bias)
+                                                             want_bias=ctx.has_bias, grad_y_max=gy_max, terms=1)
             elif split_y and ctx.x_max is not None and _f16x2_mode():
                 gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
                                                              layer._packed_linear().ktab, ctx.relu_in,
@@ -109,7 +107,7 @@ class RqsFn(torch.autograd.Function):
             grad_lad = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
         gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
                                    pre_div=pre_div, min_bin_width=mins[0], min_bin_height=mins[1],
-                                   min_derivative=mins[2], inverse=inverse, want_max=_f16x2_mode())
+                                   min_derivative=mins[2], inverse=inverse, want_max=_f16x2_mode() or _bf16_mode())
         return gx, gparams, None, None, None, None, None, None
 
 

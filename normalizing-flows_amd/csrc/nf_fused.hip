@@ -528,6 +528,19 @@ struct SplitF16x2 {
     }
 };
 
+// One scaled fp16 term per operand (11 significant bits relative to the tensor's largest element): the weight-gradient
+// GEMM of the bf16 training mode - one MFMA per product, one conversion per element.
+struct SplitF16x1 {
+    static constexpr int NT = 1;
+    static constexpr bool SCALED = true;
+    typedef _Float16 elem;
+    typedef f16x8 vec;
+    static __device__ __forceinline__ void split1(float a, elem (&t)[NT]) { t[0] = (_Float16)a; }
+    static __device__ __forceinline__ void fma_tile(f32x16& acc, const vec (&a)[NT], const vec (&b)[NT]) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+    }
+};
+
 // s = 2^e with m * 2^e in [2^13, 2^14) for the float whose bit pattern is `bits` (0 / denormal: s = 1); inv = 2^-e
 __device__ __forceinline__ void pow2_pair(unsigned bits, float& s, float& inv) {
     const int ex = (int)((bits >> 23) & 0xff) - 126;          // m = f * 2^ex, f in [0.5, 1)
@@ -958,12 +971,12 @@ struct WgradSplitArgs {
 // read the same grad_y / x chunks at the same time) land on ONE XCD and share its L2.
 // TW = 1: 128 (out) x 128 (in) tiles, 4 waves, two workgroups per CU; TW = 2: 256 x 128 tiles, 8 waves, one workgroup per
 // CU (wide layers: a quarter fewer loads and splits per product, grad_y chunks shared by half as many workgroups).
-template <int TW>
+template <int TW, class SP = SplitF16x2>
 __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const WgradSplitArgs g) {
-    typedef SplitF16x2 SP;
+    constexpr int NT = SP::NT;                       // fp16 terms per operand: 2 (f16x2, three MFMAs a product) or 1
     constexpr int YC = 128 * TW;                     // grad_y columns (output rows of grad_W) per tile
     constexpr int XO = 2 / TW;                       // x row octets per thread
-    constexpr int YSZ = 2 * YC * WSLD, XSZ = 2 * 128 * WSLD;            // one buffer: both term planes, fp16 elements
+    constexpr int YSZ = NT * YC * WSLD, XSZ = NT * 128 * WSLD;          // one buffer: all term planes, fp16 elements
     extern __shared__ __attribute__((aligned(16))) char wg_lds[];
     _Float16* const Yt = (_Float16*)wg_lds;                             // [2 buffers][2 terms][YC][WSLD]
     _Float16* const Xt = Yt + 2 * YSZ;                                  // [2 buffers][2 terms][128][WSLD]
@@ -1054,32 +1067,34 @@ __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const Wgr
         _Float16* const xt = Xt + buf * XSZ;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            SP::vec ty[2];
+            typename SP::vec ty[NT];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                SP::elem t[2];
+                typename SP::elem t[NT];
                 const float ys = c.y[o][e] * ((so_u + 2 * o) * 8 + e < left ? sy : 0.f);
                 bsum += ys;
                 SP::split1(ys, t);
-                ty[0][e] = t[0]; ty[1][e] = t[1];
+#pragma unroll
+                for (int p = 0; p < NT; ++p) ty[p][e] = t[p];
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                *reinterpret_cast<SP::vec*>(&yt[(p * YC + sc) * WSLD + (so + 2 * o) * 8]) = ty[p];
+            for (int p = 0; p < NT; ++p)
+                *reinterpret_cast<typename SP::vec*>(&yt[(p * YC + sc) * WSLD + (so + 2 * o) * 8]) = ty[p];
         }
 #pragma unroll
         for (int o = 0; o < XO; ++o) {
-            SP::vec tx[2];
+            typename SP::vec tx[NT];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                SP::elem t[2];
+                typename SP::elem t[NT];
                 const float xa = g.relu_in ? __builtin_amdgcn_fmed3f(c.x[o][e], 0.f, INFINITY) : c.x[o][e];
                 SP::split1(xa * sx, t);
-                tx[0][e] = t[0]; tx[1][e] = t[1];
+#pragma unroll
+                for (int p = 0; p < NT; ++p) tx[p][e] = t[p];
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                *reinterpret_cast<SP::vec*>(&xt[(p * 128 + xsc) * WSLD + (xso + 2 * TW * o) * 8]) = tx[p];
+            for (int p = 0; p < NT; ++p)
+                *reinterpret_cast<typename SP::vec*>(&xt[(p * 128 + xsc) * WSLD + (xso + 2 * TW * o) * 8]) = tx[p];
         }
     };
     auto mma = [&](int buf) {
@@ -1087,13 +1102,13 @@ __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const Wgr
         const _Float16* const xt = Xt + buf * XSZ;
 #pragma unroll
         for (int ks = 0; ks < WSB / 16; ++ks) {
-            SP::vec a[2][2], b[2][2];
+            typename SP::vec a[2][NT], b[2][NT];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    a[i][p] = *reinterpret_cast<const SP::vec*>(&yt[(p * YC + wr * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
-                    b[i][p] = *reinterpret_cast<const SP::vec*>(&xt[(p * 128 + wc * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
+                for (int p = 0; p < NT; ++p) {
+                    a[i][p] = *reinterpret_cast<const typename SP::vec*>(&yt[(p * YC + wr * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
+                    b[i][p] = *reinterpret_cast<const typename SP::vec*>(&xt[(p * 128 + wc * 64 + i * 32 + fr) * WSLD + ks * 16 + fb * 8]);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1996,11 +2011,10 @@ extern "C" int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, 
                                     : launch_linear_split<SplitF16x2>(g, (int)grid, lds, relu_in, s);
 }
 
-extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, const uint32_t* x_max,
-                                                 const float* grad_y, int64_t grad_y_row_stride,
-                                                 const uint32_t* grad_y_max, const float* mask, const int32_t* ktab,
-                                                 float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
-                                                 void* stream) {
+static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t* x_max, const float* grad_y,
+                            int64_t grad_y_row_stride, const uint32_t* grad_y_max, const float* mask,
+                            const int32_t* ktab, float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
+                            int terms, void* stream) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (B == 0) return NF_OK;
     if (!x || !grad_y || !grad_w || !x_max || !grad_y_max) return NF_ERR_NULL;
@@ -2024,16 +2038,39 @@ extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_s
     const int64_t grid = (work + g.group - 1) / g.group * g.group;      // whole groups, then whole rounds of 8 XCDs
     const int64_t blocks = (grid / g.group + 7) / 8 * 8 * g.group;
     if (blocks > 0x7fffffff) return NF_ERR_SHAPE;
-    static unsigned long long cap_done[2] = {0, 0};
-    const int rc = tw == 2 ? nf_raise_lds_cap((const void*)wgrad_split_kernel<2>, &cap_done[1])
-                           : nf_raise_lds_cap((const void*)wgrad_split_kernel<1>, &cap_done[0]);
+    static unsigned long long cap_done[4] = {0, 0, 0, 0};
+    const void* kern = terms == 2 ? (tw == 2 ? (const void*)wgrad_split_kernel<2, SplitF16x2> : (const void*)wgrad_split_kernel<1, SplitF16x2>)
+                                  : (tw == 2 ? (const void*)wgrad_split_kernel<2, SplitF16x1> : (const void*)wgrad_split_kernel<1, SplitF16x1>);
+    const int rc = nf_raise_lds_cap(kern, &cap_done[(terms == 2 ? 0 : 2) + (tw == 2 ? 1 : 0)]);
     if (rc != NF_OK) return rc;
-    const size_t lds = (size_t)2 * 2 * (128 * tw + 128) * WSLD * sizeof(_Float16);       // 2 buffers x 2 terms
-    if (tw == 2)
-        hipLaunchKernelGGL(wgrad_split_kernel<2>, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, g);
-    else
-        hipLaunchKernelGGL(wgrad_split_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g);
+    const size_t lds = (size_t)2 * terms * (128 * tw + 128) * WSLD * sizeof(_Float16);   // 2 buffers x terms
+    const dim3 gr((unsigned)blocks), bl(256 * tw);
+    hipStream_t s = (hipStream_t)stream;
+    if (terms == 2 && tw == 2) hipLaunchKernelGGL((wgrad_split_kernel<2, SplitF16x2>), gr, bl, lds, s, g);
+    else if (terms == 2) hipLaunchKernelGGL((wgrad_split_kernel<1, SplitF16x2>), gr, bl, lds, s, g);
+    else if (tw == 2) hipLaunchKernelGGL((wgrad_split_kernel<2, SplitF16x1>), gr, bl, lds, s, g);
+    else hipLaunchKernelGGL((wgrad_split_kernel<1, SplitF16x1>), gr, bl, lds, s, g);
     return nf_launch_status();
+}
+
+extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                                 const float* grad_y, int64_t grad_y_row_stride,
+                                                 const uint32_t* grad_y_max, const float* mask, const int32_t* ktab,
+                                                 float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
+                                                 void* stream) {
+    return wgrad_split_impl(x, x_row_stride, x_max, grad_y, grad_y_row_stride, grad_y_max, mask, ktab, grad_w, grad_b, B,
+                            in, out, relu_in, 2, stream);
+}
+
+// The same weight gradient with ONE scaled fp16 term per operand (11 significant bits relative to each tensor's
+// largest element, fp32 accumulation): the bf16 training mode's weight gradient - a third of the MFMAs.
+extern "C" int nf_masked_linear_half_bwd_weight(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                                const float* grad_y, int64_t grad_y_row_stride,
+                                                const uint32_t* grad_y_max, const float* mask, const int32_t* ktab,
+                                                float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
+                                                void* stream) {
+    return wgrad_split_impl(x, x_row_stride, x_max, grad_y, grad_y_row_stride, grad_y_max, mask, ktab, grad_w, grad_b, B,
+                            in, out, relu_in, 1, stream);
 }
 
 // ---- the one entry point that allocates nothing and takes no workspace ---------------------------------
