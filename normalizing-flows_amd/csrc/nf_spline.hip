@@ -348,13 +348,24 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     }
 }
 
+// Launch of one instantiation; more than 64 KB of dynamic LDS (many bins) needs the per-device cap raised first.
+template <auto Kern, class Args>
+int launch_spline(const Args& a, int grid, size_t lds, hipStream_t s) {
+    static unsigned long long raised = 0;
+    if (lds > 64 * 1024) {
+        if (const int e = nf_raise_lds_cap((const void*)Kern, &raised)) return e;
+    }
+    hipLaunchKernelGGL(Kern, dim3(grid), dim3(kThreads), lds, s, a);
+    return NF_OK;
+}
+
 template <int KT>
 int launch_rqs_bwd_k(const RqsBwdArgs& a, int grid, size_t lds, hipStream_t s) {
     const int nv = (kThreads * a.c.P + 4 + 3) / 4;
     const int per = (nv + kThreads - 1) / kThreads;
-    if (per <= 6) hipLaunchKernelGGL((rqs_bwd_kernel<KT, 6>), dim3(grid), dim3(kThreads), lds, s, a);
-    else if (per <= 12) hipLaunchKernelGGL((rqs_bwd_kernel<KT, 12>), dim3(grid), dim3(kThreads), lds, s, a);
-    else if (per <= 25) hipLaunchKernelGGL((rqs_bwd_kernel<KT, 25>), dim3(grid), dim3(kThreads), lds, s, a);
+    if (per <= 6) { if (const int e = launch_spline<rqs_bwd_kernel<KT, 6>>(a, grid, lds, s)) return e; }
+    else if (per <= 12) { if (const int e = launch_spline<rqs_bwd_kernel<KT, 12>>(a, grid, lds, s)) return e; }
+    else if (per <= 25) { if (const int e = launch_spline<rqs_bwd_kernel<KT, 25>>(a, grid, lds, s)) return e; }
     else return NF_ERR_SHAPE;
     return nf_launch_status();
 }
@@ -531,9 +542,9 @@ template <int KT, bool INV>
 int launch_rqs_k(const RqsArgs& a, int grid, size_t lds, hipStream_t s) {
     const int nv = (kThreads * a.c.P + 4 + 3) / 4;
     const int per = (nv + kThreads - 1) / kThreads;
-    if (per <= 6) hipLaunchKernelGGL((rqs_kernel<KT, INV, 6>), dim3(grid), dim3(kThreads), lds, s, a);
-    else if (per <= 12) hipLaunchKernelGGL((rqs_kernel<KT, INV, 12>), dim3(grid), dim3(kThreads), lds, s, a);
-    else if (per <= 25) hipLaunchKernelGGL((rqs_kernel<KT, INV, 25>), dim3(grid), dim3(kThreads), lds, s, a);
+    if (per <= 6) { if (const int e = launch_spline<rqs_kernel<KT, INV, 6>>(a, grid, lds, s)) return e; }
+    else if (per <= 12) { if (const int e = launch_spline<rqs_kernel<KT, INV, 12>>(a, grid, lds, s)) return e; }
+    else if (per <= 25) { if (const int e = launch_spline<rqs_kernel<KT, INV, 25>>(a, grid, lds, s)) return e; }
     else return NF_ERR_SHAPE;
     return nf_launch_status();
 }
@@ -553,11 +564,11 @@ template <bool INV, int FAM>
 int launch_family(const RqsArgs& a, int grid, size_t lds, hipStream_t s) {
     const int nv = (kThreads * a.c.P + 4 + 3) / 4;
     const int per = (nv + kThreads - 1) / kThreads;
-    if (per <= 6 && a.c.K == 8) hipLaunchKernelGGL((rqs_kernel<8, INV, 6, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
-    else if (per <= 6 && a.c.K == 10) hipLaunchKernelGGL((rqs_kernel<10, INV, 6, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
-    else if (per <= 6) hipLaunchKernelGGL((rqs_kernel<0, INV, 6, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
-    else if (per <= 12) hipLaunchKernelGGL((rqs_kernel<0, INV, 12, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
-    else if (per <= 25) hipLaunchKernelGGL((rqs_kernel<0, INV, 25, FAM>), dim3(grid), dim3(kThreads), lds, s, a);
+    if (per <= 6 && a.c.K == 8) { if (const int e = launch_spline<rqs_kernel<8, INV, 6, FAM>>(a, grid, lds, s)) return e; }
+    else if (per <= 6 && a.c.K == 10) { if (const int e = launch_spline<rqs_kernel<10, INV, 6, FAM>>(a, grid, lds, s)) return e; }
+    else if (per <= 6) { if (const int e = launch_spline<rqs_kernel<0, INV, 6, FAM>>(a, grid, lds, s)) return e; }
+    else if (per <= 12) { if (const int e = launch_spline<rqs_kernel<0, INV, 12, FAM>>(a, grid, lds, s)) return e; }
+    else if (per <= 25) { if (const int e = launch_spline<rqs_kernel<0, INV, 25, FAM>>(a, grid, lds, s)) return e; }
     else return NF_ERR_SHAPE;
     return nf_launch_status();
 }

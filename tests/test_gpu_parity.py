@@ -2165,3 +2165,25 @@ def test_rqs_bwd_leaves_the_gradient_scale(nf):
     _, gpe = nf._lib.rqs_bwd(e, torch.empty(0, D * 23, device='cuda'), e, torch.empty(0, device='cuda'), K, 'linear',
                              3.0, want_max=True)
     assert nf._lib.tagged_max(gpe).item() == 0
+
+
+def test_rqs_many_bins_needs_the_raised_lds_cap(nf):
+    """K = 32 (P = 95 floats per element): the staged span of 256 elements is 97 KB of LDS, past the 64 KB a kernel
+    gets without raising its cap.  Forward, inverse and backward against the oracle."""
+    g = torch.Generator().manual_seed(12)
+    B, D, K = 70, 9, 32
+    x = torch.randn(B, D, generator=g) * 2.5
+    p = torch.randn(B, D * (3 * K - 1), generator=g)
+    mins = (1e-3, 1e-3, 1e-3)
+    y, lad, bins = nf._lib.rqs(x.cuda(), p.cuda(), K, 'linear', 5.0, want_bins=True)
+    wy, wl, wb = O._rq_ar_elementwise(x.double(), p.double(), K, 5.0, False, mins, return_bins=True)
+    assert rel_err(y.cpu(), wy) < TOL and rel_err(lad.cpu(), wl) < 1e-4
+    assert (bins.cpu().long() != wb.long()).sum().item() == 0
+    xi, li, _ = nf._lib.rqs(y, p.cuda(), K, 'linear', 5.0, inverse=True)
+    assert (xi.cpu() - x).abs().max().item() < 1e-3
+    gy, gl = torch.randn(B, D, generator=g), torch.randn(B, generator=g)
+    gx, gp = nf._lib.rqs_bwd(x.cuda(), p.cuda(), gy.cuda(), gl.cuda(), K, 'linear', 5.0)
+    x64, p64 = x.double().requires_grad_(True), p.double().requires_grad_(True)
+    oy, ol = O._rq_ar_elementwise(x64, p64, K, 5.0, False, mins)
+    ((oy * gy.double()).sum() + (ol * gl.double()).sum()).backward()
+    assert _nerr(gx.cpu(), x64.grad) < 2e-3 and _nerr(gp.cpu(), p64.grad) < 2e-3
