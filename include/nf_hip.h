@@ -256,6 +256,12 @@ size_t nf_resnet_blob_floats(int n_in, int hidden, int num_blocks);
 int nf_resnet_hidden_fwd(const float* x, int64_t x_row_stride, const int32_t* in_index, int n_in, int row_width,
                          const float* blob, int hidden, int num_blocks, float* h, int64_t h_row_stride,
                          int64_t B, void* stream);
+/* The same launch, also writing the gathered columns to copy_out[b, in_index[c]] (rows `copy_row_stride` apart): the
+ * identity half of a coupling layer reaches the layer's output (transforms.py:98-106) without a copy of the whole
+ * input; the transformed half is then written by nf_coupling_rqs_fwd into the same buffer. */
+int nf_resnet_hidden_fwd_copy(const float* x, int64_t x_row_stride, const int32_t* in_index, int n_in, int row_width,
+                              const float* blob, int hidden, int num_blocks, float* h, int64_t h_row_stride,
+                              float* copy_out, int64_t copy_row_stride, int64_t B, void* stream);
 
 /* ---- autoregressive inverse, row-resident (replaces the D conditioner passes of transforms.py:493-500
  *      for MaskedPiecewiseRationalQuadraticAutoregressiveTransform, made.py:352-359 + rational_quadratic.py) ----

@@ -118,6 +118,9 @@ _SIGNATURES = {
     'nf_resnet_blob_floats': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_resnet_hidden_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p,
                                         _c.c_int, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p]),
+    'nf_resnet_hidden_fwd_copy': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p,
+                                             _c.c_int, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                             _c.c_int64, _c.c_void_p]),
     'nf_made_rqs_inverse_rows_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     'nf_made_inverse_blob_floats': (_c.c_size_t, [_c.c_int, _c.c_int]),
     'nf_made_rqs_inverse_rows': (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64,
@@ -790,9 +793,10 @@ def resnet_hidden_supported(n_in, hidden):
     return 0 < n_in <= 128 and 0 < hidden <= 128 and hidden % 32 == 0
 
 
-def resnet_hidden(x, in_index, blob, n_in, hidden, num_blocks):
+def resnet_hidden(x, in_index, blob, n_in, hidden, num_blocks, copy_out=None):
     """Hidden state [B, hidden] of a ResidualNet (blob layout: nf_resnet_blob_floats) on columns `in_index`
-    (int32, or None for the first n_in) of x."""
+    (int32, or None for the first n_in) of x.  copy_out: a [B, width] tensor that receives those columns of x at the
+    same positions (nf_resnet_hidden_fwd_copy)."""
     lib = load()
     _dev(x, 'inputs')
     _dev(blob, 'blob')
@@ -807,7 +811,16 @@ def resnet_hidden(x, in_index, blob, n_in, hidden, num_blocks):
     B = x.shape[0]
     h = torch.empty((B, hidden), dtype=torch.float32, device=x.device)
 
+    if copy_out is not None:
+        _dev(copy_out, 'copy_out')
+        if copy_out.shape != x.shape:
+            raise ValueError('copy_out must have the shape of the inputs')
+        cp, cs = _rows(copy_out, 'copy_out')
+
     def launch():
+        if copy_out is not None:
+            return lib.nf_resnet_hidden_fwd_copy(xp, xs, _ptr(in_index), n_in, x.shape[1], blob.data_ptr(), hidden,
+                                                 num_blocks, h.data_ptr(), hidden, cp, cs, B, _stream())
         return lib.nf_resnet_hidden_fwd(xp, xs, _ptr(in_index), n_in, x.shape[1], blob.data_ptr(), hidden, num_blocks,
                                         h.data_ptr(), hidden, B, _stream())
     with torch.cuda.device(x.device):

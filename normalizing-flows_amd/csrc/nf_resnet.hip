@@ -32,6 +32,8 @@ struct ResnetArgs {
     float* h;
     int64_t ldh;
     int64_t M;
+    float* copy_out;            // nullable: the gathered input columns are also written to copy_out[:, in_index[c]]
+    int64_t ldc;
 };
 
 // dst[64][hidden] (+)= act(src[64][K]) @ W[hidden][K]^T + bias; act(v) = relu(v * sc[k] + sh[k]) when ACT.
@@ -89,7 +91,11 @@ __global__ __launch_bounds__(RT) void resnet_hidden_kernel(const ResnetArgs g) {
     for (int e = tid; e < RM * g.kp; e += RT) {
         const int r = e / g.kp, c = e - r * g.kp;
         float v = 0.f;
-        if (m0 + r < g.M && c < g.n_in) v = g.x[(m0 + r) * g.ldx + (g.in_index ? g.in_index[c] : c)];
+        if (m0 + r < g.M && c < g.n_in) {
+            const int col = g.in_index ? g.in_index[c] : c;
+            v = g.x[(m0 + r) * g.ldx + col];
+            if (g.copy_out) g.copy_out[(m0 + r) * g.ldc + col] = v;      // a coupling layer's identity half passes through
+        }
         T[r * ld + c] = v;
     }
     __syncthreads();
@@ -124,9 +130,9 @@ extern "C" size_t nf_resnet_blob_floats(int n_in, int hidden, int num_blocks) {
     return h * kp + h + (size_t)num_blocks * (2 * (2 * h + h * h + h));
 }
 
-extern "C" int nf_resnet_hidden_fwd(const float* x, int64_t x_row_stride, const int32_t* in_index, int n_in,
-                                    int row_width, const float* blob, int hidden, int num_blocks, float* h,
-                                    int64_t h_row_stride, int64_t B, void* stream) {
+static int resnet_hidden_impl(const float* x, int64_t x_row_stride, const int32_t* in_index, int n_in,
+                              int row_width, const float* blob, int hidden, int num_blocks, float* h,
+                              int64_t h_row_stride, float* copy_out, int64_t copy_row_stride, int64_t B, void* stream) {
     if (B < 0 || n_in <= 0 || n_in > MAXW || hidden <= 0 || hidden > MAXW || hidden % 32 != 0 || num_blocks < 0 ||
         row_width < n_in)
         return NF_ERR_SHAPE;
@@ -138,6 +144,7 @@ extern "C" int nf_resnet_hidden_fwd(const float* x, int64_t x_row_stride, const 
     ResnetArgs g;
     g.x = x; g.ldx = x_row_stride; g.in_index = in_index; g.n_in = n_in; g.kp = (n_in + 7) / 8 * 8;
     g.blob = blob; g.hidden = hidden; g.num_blocks = num_blocks; g.h = h; g.ldh = h_row_stride; g.M = B;
+    g.copy_out = copy_out; g.ldc = copy_row_stride;
     const int wmax = g.kp > hidden ? g.kp : hidden;
     const size_t lds = sizeof(float) * 2 * RM * (size_t)(wmax + 4);
     const int64_t grid = (B + RM - 1) / RM;
@@ -147,4 +154,23 @@ extern "C" int nf_resnet_hidden_fwd(const float* x, int64_t x_row_stride, const 
     if (rc != NF_OK) return rc;
     hipLaunchKernelGGL(resnet_hidden_kernel, dim3((unsigned)grid), dim3(RT), lds, (hipStream_t)stream, g);
     return nf_launch_status();
+}
+
+extern "C" int nf_resnet_hidden_fwd(const float* x, int64_t x_row_stride, const int32_t* in_index, int n_in,
+                                    int row_width, const float* blob, int hidden, int num_blocks, float* h,
+                                    int64_t h_row_stride, int64_t B, void* stream) {
+    return resnet_hidden_impl(x, x_row_stride, in_index, n_in, row_width, blob, hidden, num_blocks, h, h_row_stride,
+                              nullptr, 0, B, stream);
+}
+
+// The same launch also copies the gathered columns into `copy_out` (same column positions): a coupling layer's identity
+// half reaches the layer's output without the `outputs = inputs.clone()` pass (transforms.py:98-106 writes both halves).
+extern "C" int nf_resnet_hidden_fwd_copy(const float* x, int64_t x_row_stride, const int32_t* in_index, int n_in,
+                                         int row_width, const float* blob, int hidden, int num_blocks, float* h,
+                                         int64_t h_row_stride, float* copy_out, int64_t copy_row_stride, int64_t B,
+                                         void* stream) {
+    if (!copy_out && B > 0) return NF_ERR_NULL;
+    if (copy_row_stride < row_width) return NF_ERR_LAYOUT;
+    return resnet_hidden_impl(x, x_row_stride, in_index, n_in, row_width, blob, hidden, num_blocks, h, h_row_stride,
+                              copy_out, copy_row_stride, B, stream);
 }

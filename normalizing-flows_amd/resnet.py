@@ -121,10 +121,11 @@ class ResidualNet(nn.Module):
                 and all(_is_relu(b.activation) for b in self.blocks)
                 and _lib.resnet_hidden_supported(self.initial_layer.in_features, self.hidden_features))
 
-    def forward_hidden_columns(self, inputs, columns):
-        """forward_hidden(inputs[:, columns]) without materialising the gather; `columns` int32 on the device."""
+    def forward_hidden_columns(self, inputs, columns, copy_out=None):
+        """forward_hidden(inputs[:, columns]) without materialising the gather; `columns` int32 on the device.
+        copy_out: receives those columns of `inputs` at the same positions (the coupling layer's identity half)."""
         return _lib.resnet_hidden(inputs, columns, self._hidden_blob(), self.initial_layer.in_features,
-                                  self.hidden_features, len(self.blocks))
+                                  self.hidden_features, len(self.blocks), copy_out=copy_out)
 
     def forward_hidden(self, inputs, context=None):
         """Everything but the final layer (which the coupling transforms fuse with their spline)."""

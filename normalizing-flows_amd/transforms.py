@@ -648,12 +648,15 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
             inputs = inputs.contiguous()
         net = self.transform_net
         if net.hidden_stack_fusable(inputs, context):
-            hidden = net.forward_hidden_columns(inputs, self._index32('identity_features'))
+            # the hidden-stack launch reads the identity columns anyway: it also drops them into the output, the
+            # fused launch below writes the transformed columns - every column written once, no clone of the input
+            outputs = torch.empty_like(inputs)
+            hidden = net.forward_hidden_columns(inputs, self._index32('identity_features'), copy_out=outputs)
         else:
             hidden = net.forward_hidden(inputs[:, self.identity_features].contiguous(), context)
+            outputs = inputs.clone()                   # identity columns pass through
         pf = net.final_layer._packed_fused_final(self.num_transform_features, self.num_bins, self.tails,
                                                  logit_div=self._pre_div())
-        outputs = inputs.clone()                       # identity columns pass through
         _, logabsdet, bins = _lib.made_rqs(hidden, pf, inputs, self.tail_bound, inverse=inverse, out=outputs,
                                            min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                                            min_derivative=self.min_derivative, feat_index=self._feat_index(),
