@@ -2187,3 +2187,54 @@ def test_rqs_many_bins_needs_the_raised_lds_cap(nf):
     oy, ol = O._rq_ar_elementwise(x64, p64, K, 5.0, False, mins)
     ((oy * gy.double()).sum() + (ol * gl.double()).sum()).backward()
     assert _nerr(gx.cpu(), x64.grad) < 2e-3 and _nerr(gp.cpu(), p64.grad) < 2e-3
+
+
+def test_round2_entry_points_edge_cases(nf):
+    """Empty batches, strided rows and argument errors of the entry points added in round 2."""
+    L = nf._lib
+    dev0 = dict(device='cuda')
+    for kind, P in (('linear', 6), ('quadratic', 13), ('cubic', 14)):
+        e = torch.empty(0, 5, **dev0)
+        y, lad, _ = L.family_spline(kind, e, torch.empty(0, 5 * P, **dev0), 6, tail_bound=10.0)
+        assert y.shape == (0, 5) and lad.shape == (0,)
+        gx, gp = L.family_spline_bwd(kind, e, torch.empty(0, 5 * P, **dev0), e, torch.empty(0, **dev0), 6, tail_bound=10.0)
+        assert gx.shape == (0, 5) and gp.shape == (0, 5 * P)
+    # family backward on row views (x, grad_y with a wider row stride) equals the contiguous call
+    g = torch.Generator(device='cuda').manual_seed(2)
+    B, D, K = 130, 7, 8
+    big = torch.rand(B, D + 5, device='cuda', generator=g) * 0.9 + 0.05
+    bgy = torch.randn(B, D + 3, device='cuda', generator=g)
+    p = torch.randn(B, D * (2 * K + 1), device='cuda', generator=g)
+    gl = torch.randn(B, device='cuda', generator=g)
+    a = L.family_spline_bwd('quadratic', big[:, :D], p, bgy[:, :D], gl, K)
+    b = L.family_spline_bwd('quadratic', big[:, :D].contiguous(), p, bgy[:, :D].contiguous(), gl, K)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with pytest.raises(ValueError):                      # the reference's error (quadratic.py:64-67), backward too
+        L.family_spline_bwd('quadratic', big[:, :D], p, bgy[:, :D], gl, K, min_bin_width=0.5)
+    with pytest.raises(Exception):                       # parameter rows of the wrong width
+        L.family_spline_bwd('cubic', big[:, :D], p, bgy[:, :D], gl, K)
+    # std-normal log-density: empty batch, strided rows, with and without a logdet
+    z = torch.randn(33, 9, device='cuda', generator=g)
+    lad = torch.randn(33, device='cuda', generator=g)
+    want = -0.5 * (z.double() ** 2).sum(1) - 0.5 * 9 * np.log(2 * np.pi)
+    assert rel_err(L.std_normal_log_prob(z).cpu(), want.cpu()) < 1e-6
+    assert rel_err(L.std_normal_log_prob(z, lad, -1.0).cpu(), (want - lad.double()).cpu()) < 1e-6
+    zs = torch.randn(33, 16, device='cuda', generator=g)
+    assert torch.equal(L.std_normal_log_prob(zs[:, :9]), L.std_normal_log_prob(zs[:, :9].contiguous()))
+    assert L.std_normal_log_prob(torch.empty(0, 9, **dev0)).shape == (0,)
+    # hidden-stack launch with copy-through: identity columns land in the output, nothing else is touched
+    mask = torch.zeros(8)
+    mask[::2] = 1
+    c = nf.PiecewiseRationalQuadraticCouplingTransform(mask, lambda i, o: nf.ResidualNet(i, o, hidden_features=32, num_blocks=2),
+                                                       num_bins=8, tails='linear', tail_bound=3.0).cuda().eval()
+    x = torch.randn(70, 8, device='cuda', generator=g)
+    out = torch.full_like(x, 7.0)
+    idx = c._index32('identity_features')
+    h0 = c.transform_net.forward_hidden_columns(x, idx)
+    h1 = c.transform_net.forward_hidden_columns(x, idx, copy_out=out)
+    assert torch.equal(h0, h1)
+    assert torch.equal(out[:, c.identity_features], x[:, c.identity_features])
+    assert (out[:, c.transform_features] == 7.0).all()
+    with torch.no_grad():
+        y, _ = c(x)
+    assert torch.equal(y[:, c.identity_features], x[:, c.identity_features])
