@@ -250,16 +250,27 @@ __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, flo
         mw = fmaxf(mw, raw(uw, k));
         mh = fmaxf(mh, raw(uh, k));
     }
+    // KT > 0: widths / heights in registers (static indices only: the search loop below also picks the bin's and its
+    // two neighbours' values); otherwise CACHE keeps them over the logits in LDS
+    constexpr int KA = KT > 0 ? KT : 1;
+    float wv[KA], hv[KA];
     float sw = 0.0f, sh_ = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const float ew = nf_exp(raw(uw, k) - mw), eh = nf_exp(raw(uh, k) - mh);
-        if constexpr (CACHE) { uw[k] = ew; uh[k] = eh; }
+        if constexpr (KT > 0) { wv[k] = ew; hv[k] = eh; }
+        else if constexpr (CACHE) { uw[k] = ew; uh[k] = eh; }
         sw += ew;
         sh_ += eh;
     }
     const NfDivisor dw = nf_divisor(sw), dh = nf_divisor(sh_);
-    if constexpr (CACHE) {
+    if constexpr (KT > 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            wv[k] = a.min_w + a.scale_w * nf_div_ieee(wv[k], dw);
+            hv[k] = a.min_h + a.scale_h * nf_div_ieee(hv[k], dh);
+        }
+    } else if constexpr (CACHE) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             uw[k] = a.min_w + a.scale_w * nf_div_ieee(uw[k], dw);
@@ -267,17 +278,20 @@ __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, flo
         }
     }
     auto width = [&](int k) {
-        if constexpr (CACHE) return uw[k];
+        if constexpr (KT > 0) return wv[k];
+        else if constexpr (CACHE) return uw[k];
         else return a.min_w + a.scale_w * nf_div_ieee(nf_exp(raw(uw, k) - mw), dw);
     };
     auto height = [&](int k) {
-        if constexpr (CACHE) return uh[k];
+        if constexpr (KT > 0) return hv[k];
+        else if constexpr (CACHE) return uh[k];
         else return a.min_h + a.scale_h * nf_div_ieee(nf_exp(raw(uh, k) - mh), dh);
     };
     // bin search over the running sums
     double accw = 0.0, acch = 0.0;
     float cw0 = 0.0f, ch0 = 0.0f, lw = 0.0f, rw = 1.0f, d = 0.0f;
     int b = 0;
+    float wb = 1.0f, hb = 1.0f, w0 = 1.0f, h0 = 1.0f, w1 = 1.0f, h1 = 1.0f;      // bin b and its neighbours (KT > 0)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         accw += (double)width(k);
@@ -288,30 +302,40 @@ __device__ __forceinline__ void cubic_eval(PT p, float x, const RqsConst& a, flo
             ch1 = INV ? 1.0f + 1e-6f : 1.0f;
         }
         const bool ge = INV ? (t >= ch0) : (t >= cw0);
-        if (ge) { b = k; lw = cw0; rw = cw1; d = ch0; }
+        if (ge) {
+            b = k; lw = cw0; rw = cw1; d = ch0;
+            if constexpr (KT > 0) {
+                wb = wv[k]; hb = hv[k];
+                if (k > 0) { w0 = wv[k - 1]; h0 = hv[k - 1]; }
+                if (k < KT - 1) { w1 = wv[k + 1]; h1 = hv[k + 1]; }
+            }
+        }
         cw0 = cw1;
         ch0 = ch1;
     }
+    if constexpr (KT == 0) {
+        wb = width(b); hb = height(b);
+        if (b > 0) { w0 = width(b - 1); h0 = height(b - 1); }
+        if (b < K - 1) { w1 = width(b + 1); h1 = height(b + 1); }
+    }
     // knot derivatives at the two ends of bin b
-    const float wb = width(b), sb = height(b) / wb;
-    auto interior = [&](float w0, float s0, float w1, float s1) {      // knot between bins (w0, s0) and (w1, s1)
-        const float m1 = fminf(fabsf(s0), fabsf(s1));
-        const float m2 = 0.5f * (w1 * s0 + w0 * s1) / (w0 + w1);
-        const float sg0 = (s0 > 0.f) - (s0 < 0.f), sg1 = (s1 > 0.f) - (s1 < 0.f);
+    const float sb = hb / wb;
+    auto interior = [&](float wl, float sl, float wr, float sr) {      // knot between bins (wl, sl) and (wr, sr)
+        const float m1 = fminf(fabsf(sl), fabsf(sr));
+        const float m2 = 0.5f * (wr * sl + wl * sr) / (wl + wr);
+        const float sg0 = (sl > 0.f) - (sl < 0.f), sg1 = (sr > 0.f) - (sr < 0.f);
         return fminf(m1, m2) * (sg0 + sg1);
     };
     float dl, dr;
     if (b == 0) {
         dl = (1.0f / (1.0f + nf_exp(-p[2 * K]))) * 3.0f * sb;
     } else {
-        const float w0 = width(b - 1);
-        dl = interior(w0, height(b - 1) / w0, wb, sb);
+        dl = interior(w0, h0 / w0, wb, sb);
     }
     if (b == K - 1) {
         dr = (1.0f / (1.0f + nf_exp(-p[2 * K + 1]))) * 3.0f * sb;
     } else {
-        const float w1 = width(b + 1);
-        dr = interior(wb, sb, w1, height(b + 1) / w1);
+        dr = interior(wb, sb, w1, h1 / w1);
     }
     const float ca = (dl + dr - 2.0f * sb) / (wb * wb);
     const float cb = (3.0f * sb - 2.0f * dl - dr) / wb;
