@@ -2238,3 +2238,27 @@ def test_round2_entry_points_edge_cases(nf):
     with torch.no_grad():
         y, _ = c(x)
     assert torch.equal(y[:, c.identity_features], x[:, c.identity_features])
+
+
+def test_spline_kernels_on_unaligned_parameter_rows(nf):
+    """A parameter tensor that does not start on a 16-byte boundary (legal at the C ABI) takes the scalar staging path
+    of the spline kernels: same bits as the aligned call, forward, inverse and backward, RQ and a family."""
+    g = torch.Generator(device='cuda').manual_seed(21)
+    B, D, K = 333, 11, 8
+    x = torch.randn(B, D, device='cuda', generator=g) * 2
+    gy, gl = torch.randn(B, D, device='cuda', generator=g), torch.randn(B, device='cuda', generator=g)
+    for P, fwd, bwd in (
+            (3 * K - 1, lambda p, inv: nf._lib.rqs(x, p, K, 'linear', 3.0, inverse=inv, want_bins=True),
+             lambda p: nf._lib.rqs_bwd(x, p, gy, gl, K, 'linear', 3.0)),
+            (2 * K + 2, lambda p, inv: nf._lib.cubic_spline(x, p, K, tails='linear', bound=3.0, inverse=inv, want_bins=True),
+             lambda p: nf._lib.family_spline_bwd('cubic', x, p, gy, gl, K, tails='linear', tail_bound=3.0))):
+        buf = torch.randn(B * D * P + 3, device='cuda', generator=g)
+        for off in (1, 2, 3):
+            pu = buf[off:off + B * D * P].view(B, D * P)
+            assert pu.data_ptr() % 16 != 0
+            pa = pu.clone()
+            for inv in (False, True):
+                a, b = fwd(pa, inv), fwd(pu, inv)
+                assert all(torch.equal(u, v) for u, v in zip(a, b))
+            a, b = bwd(pa), bwd(pu)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
