@@ -8,7 +8,7 @@ from .transforms import CompositeTransform, AutoregressiveTransform, MaskedAffin
     MaskedPiecewiseRationalQuadraticAutoregressiveTransform, MaskedPiecewiseLinearAutoregressiveTransform, \
     MaskedPiecewiseQuadraticAutoregressiveTransform, MaskedPiecewiseCubicAutoregressiveTransform, \
     PiecewiseCubicCouplingTransform, CouplingTransform, AffineCouplingTransform, \
-    PiecewiseRationalQuadraticCouplingTransform, PiecewiseRationalQuadraticCDF
+    PiecewiseRationalQuadraticCouplingTransform, PiecewiseRationalQuadraticCDF, PiecewiseCubicCDF
 from . import parallel, metrics
 from .checkpoint import save_checkpoint, load_checkpoint
 from .flows import MaskedAutoregressiveFlow, SimpleMADE, SimpleMaskedLinear, apply_flow_to_samples, \

@@ -755,9 +755,14 @@ class PiecewiseCubicCouplingTransform(CouplingTransform):
         self.min_bin_height = min_bin_height
         self.tails = tails
         self.tail_bound = tail_bound
-        if apply_unconditional_transform or img_shape:
-            raise NotImplementedError('unconditional / image transforms are outside this path')
-        super().__init__(mask, transform_net_create_fn, unconditional_transform=None)
+        if img_shape:
+            raise NotImplementedError('image (4-D) inputs are outside this path')
+        unconditional_transform = None
+        if apply_unconditional_transform:
+            unconditional_transform = lambda features: PiecewiseCubicCDF(       # noqa: E731
+                shape=[features], num_bins=num_bins, tails=tails, tail_bound=tail_bound, min_bin_width=min_bin_width,
+                min_bin_height=min_bin_height)
+        super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
 
     def _transform_dim_multiplier(self):
         return self.num_bins * 2 + 2
@@ -787,3 +792,48 @@ class PiecewiseCubicCouplingTransform(CouplingTransform):
                           min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                           num_features=self.num_transform_features)
 
+
+class PiecewiseCubicCDF(nn.Module):
+    """Elementwise cubic spline with LEARNED, batch-independent parameters (reference transforms.py:417-473): what
+    `apply_unconditional_transform=True` puts on a cubic coupling layer's identity half.  `shape` = [features].  With
+    tails=None the reference's class calls the dangling name `splines.cubic_spline` (AttributeError there); here it
+    is the spline on its default interval [-10, 10] (cubic.py:56-67), like the autoregressive cubic transform."""
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1., min_bin_width=DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=DEFAULT_MIN_BIN_HEIGHT):
+        super().__init__()
+        shape = list(shape)
+        if len(shape) != 1:
+            raise NotImplementedError('image (4-D) inputs are outside this path')
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.tail_bound = tail_bound
+        self.tails = tails
+        self.unnormalized_widths = nn.Parameter(torch.randn(*shape, num_bins))
+        self.unnormalized_heights = nn.Parameter(torch.randn(*shape, num_bins))
+        self.unnorm_derivatives_left = nn.Parameter(torch.randn(*shape, 1))
+        self.unnorm_derivatives_right = nn.Parameter(torch.randn(*shape, 1))
+
+    def _spline(self, inputs, inverse=False):
+        if self.tails not in (None, 'linear'):
+            raise RuntimeError('{} tails are not implemented.'.format(self.tails))
+        _check_2d(inputs, self.unnormalized_widths.shape[0])
+        B = inputs.shape[0]
+        inputs = inputs.contiguous()
+        row = torch.cat([self.unnormalized_widths, self.unnormalized_heights, self.unnorm_derivatives_left,
+                         self.unnorm_derivatives_right], dim=-1)
+        params = row.reshape(1, -1).expand(B, -1).contiguous()       # the kernel reads one parameter row per sample
+        cfg = dict(num_bins=self.num_bins, tails=self.tails, tail_bound=10.0 if self.tails is None else self.tail_bound,
+                   min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height)
+        if torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad):
+            from .autograd import FamilySplineFn
+            return FamilySplineFn.apply(inputs, params, 'cubic', cfg, bool(inverse))
+        y, lad, _ = _lib.family_spline('cubic', inputs, params, inverse=inverse, **cfg)
+        return y, lad
+
+    def forward(self, inputs, context=None):
+        return self._spline(inputs, inverse=False)
+
+    def inverse(self, inputs, context=None):
+        return self._spline(inputs, inverse=True)

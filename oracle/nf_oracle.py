@@ -349,6 +349,41 @@ def rq_cdf(sd, x, tails, tail_bound, inverse=False, mins=(1e-3, 1e-3, 1e-3), pre
     return y, sum_except_batch(ld)
 
 
+def cubic_cdf(sd, x, tails, tail_bound, inverse=False, mins=(1e-3, 1e-3), prefix='unconditional_transform.'):
+    """PiecewiseCubicCDF: learned parameters shared across the batch.  transforms.py:417-473 (with tails=None the
+    reference calls the dangling `splines.cubic_spline`; read as cubic.py:56-221 on its default interval)."""
+    b = x.shape[0]
+    uw = sd[prefix + 'unnormalized_widths'][None, ...].expand(b, -1, -1)
+    uh = sd[prefix + 'unnormalized_heights'][None, ...].expand(b, -1, -1)
+    ul = sd[prefix + 'unnorm_derivatives_left'][None, ...].expand(b, -1, -1)
+    ur = sd[prefix + 'unnorm_derivatives_right'][None, ...].expand(b, -1, -1)
+    if tails is None:
+        y, ld = cubic_spline(x, uw, uh, ul, ur, inverse=inverse, min_bin_width=mins[0], min_bin_height=mins[1])
+    else:
+        y, ld = unconstrained_cubic_spline(x, uw, uh, ul, ur, inverse=inverse, tail_bound=tail_bound,
+                                           min_bin_width=mins[0], min_bin_height=mins[1])
+    return y, sum_except_batch(ld)
+
+
+def cubic_coupling(sd, x, num_bins, tails, tail_bound, hidden_features, inverse=False, mins=(1e-3, 1e-3),
+                   unconditional=False):
+    """Cubic coupling layer, ResidualNet conditioner.  transforms.py:349-415 (logits / sqrt(hidden_features))."""
+    def elementwise(xt, params):
+        tp = params.reshape(xt.shape[0], xt.shape[1], -1)
+        uw = tp[..., :num_bins] / np.sqrt(hidden_features)
+        uh = tp[..., num_bins:2 * num_bins] / np.sqrt(hidden_features)
+        ul, ur = tp[..., 2 * num_bins:2 * num_bins + 1], tp[..., 2 * num_bins + 1:]
+        if tails is None:
+            yy, ll = cubic_spline(xt, uw, uh, ul, ur, inverse=inverse, min_bin_width=mins[0], min_bin_height=mins[1])
+        else:
+            yy, ll = unconstrained_cubic_spline(xt, uw, uh, ul, ur, inverse=inverse, tail_bound=tail_bound,
+                                                min_bin_width=mins[0], min_bin_height=mins[1])
+        return yy, sum_except_batch(ll)
+
+    unc = (lambda v, inv: cubic_cdf(sd, v, tails, tail_bound, inverse=inv, mins=mins)) if unconditional else None
+    return _coupling(sd, x, elementwise, unconditional=unc, inverse=inverse)
+
+
 def _coupling(sd, x, elementwise, unconditional=None, inverse=False):
     """Split by index buffers, conditioner on identity half, scatter.  transforms.py:80-135.
     unconditional(ident, inverse) -> (ident', logabsdet): the identity half's own transform (:98-101 after the

@@ -403,6 +403,42 @@ def gen_unconditional_coupling():
              n_layers=len(comp._transforms), **sd_np(comp.state_dict(), 'sd/'))
 
 
+def gen_cubic_unconditional():
+    """Cubic coupling layers with apply_unconditional_transform=True (transforms.py:367-375: a PiecewiseCubicCDF,
+    :417-473, on the identity half), linear tails (with tails=None the reference's CDF calls the dangling name
+    `splines.cubic_spline`); forward and inverse."""
+    D, K, T, Hn, L = 9, 6, 3.0, 32, 2
+    torch.manual_seed(46)
+    layers = []
+    for j in range(L):
+        mask = helper_functions.create_alternating_binary_mask(D, even=(j % 2 == 0))
+        layers.append(transforms.PiecewiseCubicCouplingTransform(
+            mask=mask,
+            transform_net_create_fn=lambda i, o: resnet.ResidualNet(i, o, hidden_features=Hn, num_blocks=2),
+            num_bins=K, tails='linear', tail_bound=T, apply_unconditional_transform=True))
+    comp = transforms.CompositeTransform(layers).eval()
+    x = torch.randn(128, D) * 1.5
+    with torch.no_grad():
+        for n_, p in comp.named_parameters():
+            if 'unconditional' not in n_:
+                p.mul_(1.5)
+        y, ld = comp(x)
+        xi, ldi = comp.inverse(y)
+        with f64():
+            y64, ld64 = comp.double()(x.double())
+            xi64, ldi64 = comp.inverse(y64)
+        comp.float()
+    save('cubic_coupling_uncond_linear', x=x, y=y, ld=ld, inv_of_y=xi, inv_of_y_ld=ldi, y64=y64, ld64=ld64,
+         inv_of_y64=xi64, inv_of_y64_ld=ldi64, num_bins=K, tail_bound=T, hidden=Hn, features=D,
+         n_layers=L, **sd_np(comp.state_dict(), 'sd/'))
+    try:
+        bad = transforms.PiecewiseCubicCDF(shape=[3], num_bins=K)
+        bad(torch.rand(4, 3))
+        print('PiecewiseCubicCDF(tails=None) ran in the reference')
+    except Exception as e:      # noqa: BLE001
+        print('PiecewiseCubicCDF(tails=None) in the reference raises %s: %s' % (type(e).__name__, e))
+
+
 # ======================================================================= F5: legacy MAF (fp64)
 def gen_maf():
     torch.set_default_dtype(torch.float64)            # what main.py:21-24 selects on CPU
@@ -523,6 +559,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'maf_training':
         gen_maf_training()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'cubic_unconditional':
+        gen_cubic_unconditional()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'activations':
         gen_activations()
         sys.exit(0)
@@ -537,3 +576,4 @@ if __name__ == '__main__':
     gen_maf_training()
     gen_unconditional_coupling()
     gen_activations()
+    gen_cubic_unconditional()

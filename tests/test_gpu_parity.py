@@ -2262,3 +2262,61 @@ def test_spline_kernels_on_unaligned_parameter_rows(nf):
                 assert all(torch.equal(u, v) for u, v in zip(a, b))
             a, b = bwd(pa), bwd(pu)
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_cubic_coupling_with_unconditional_transform_golden(nf):
+    """PiecewiseCubicCouplingTransform(apply_unconditional_transform=True) = a PiecewiseCubicCDF on the identity half
+    (reference transforms.py:367-375, :417-473): the reference's state_dict loads strictly, forward / inverse against
+    its float64 results (the cubic's fp32 noise bars), gradients of every parameter against fp64 autograd through the
+    oracle; the CDF alone with tails=None runs on the spline's default interval."""
+    fx = load_golden('cubic_coupling_uncond_linear')
+    K, Tb, Hn, L, D = (int(fx['num_bins']), float(fx['tail_bound']), int(fx['hidden']), int(fx['n_layers']),
+                       int(fx['features']))
+    sd = golden_state_dict(fx)
+    layers = []
+    for j in range(L):
+        mask = sd['_transforms.%d.identity_features' % j]
+        m = torch.zeros(D)
+        m[mask] = -1.0                                   # identity features carry mask <= 0 (transforms.py:50-52)
+        m[m == 0] = 1.0
+        layers.append(nf.PiecewiseCubicCouplingTransform(
+            m, lambda i, o: nf.ResidualNet(i, o, hidden_features=Hn, num_blocks=2), num_bins=K, tails='linear',
+            tail_bound=Tb, apply_unconditional_transform=True))
+    comp = nf.CompositeTransform(layers)
+    comp.load_state_dict(sd, strict=True)
+    comp = comp.cuda().eval()
+    with torch.no_grad():
+        y, ld = comp(dev(fx['x']))
+        xi, ldi = comp.inverse(dev(fx['y']))
+    _assert_close_noisy(y, fx['y64'], fx['y'])
+    _assert_close_noisy(ld, fx['ld64'], fx['ld'])
+    assert torch.quantile((xi.cpu() - T(fx['x'])).abs().reshape(-1), 0.99).item() < 1e-3
+    # gradients, forward direction
+    g = torch.Generator().manual_seed(3)
+    x = T(fx['x'])
+    r1, r2 = torch.randn(x.shape, generator=g), torch.randn(x.shape[0], generator=g)
+    xg = x.cuda().requires_grad_(True)
+    yy, ll = comp(xg)
+    ((yy * r1.cuda()).sum() + (ll * r2.cuda()).sum()).backward()
+    sd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    l64 = [O.split_state_dict(sd64, j) for j in range(L)]
+    x64 = x.double().requires_grad_(True)
+    oy, ol = O.composite([lambda v, s=s: O.cubic_coupling(s, v, K, 'linear', Tb, Hn, unconditional=True) for s in l64], x64)
+    ((oy * r1.double()).sum() + (ol * r2.double()).sum()).backward()
+    assert _nerr(xg.grad.cpu(), x64.grad) < 2e-3
+    named, checked = dict(comp.named_parameters()), 0
+    for k, v in sd64.items():
+        if k in named and v.is_floating_point() and v.grad is not None and v.grad.abs().max() > 0:
+            assert _nerr(named[k].grad.cpu(), v.grad) < 2e-3, (k, _nerr(named[k].grad.cpu(), v.grad))
+            checked += 1
+    assert checked >= 8 * L and any('unconditional_transform' in k for k in named)
+    # the CDF on its own, default interval
+    cdf = nf.PiecewiseCubicCDF([5], num_bins=K).cuda()
+    z = (torch.rand(40, 5, device='cuda') * 2 - 1) * 9
+    with torch.no_grad():
+        a, la = cdf(z)
+        b, lb = cdf.inverse(a)
+    csd = {'unconditional_transform.' + k: v.detach().cpu().double() for k, v in cdf.state_dict().items()}
+    wa, wl = O.cubic_cdf(csd, z.cpu().double(), None, 1.0)
+    _assert_close_noisy(a, wa, wa.float())
+    assert torch.quantile((b - z).abs().reshape(-1), 0.99).item() < 1e-3

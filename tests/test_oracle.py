@@ -355,3 +355,23 @@ def test_maf_training_first_steps_follow_the_reference():
         opt.step()
         sched.step()
         assert abs(loss.item() - float(fx['loss'][step])) < 1e-9 * max(1.0, abs(float(fx['loss'][step]))), step
+
+
+def test_cubic_coupling_with_unconditional_transform():
+    """PiecewiseCubicCouplingTransform(apply_unconditional_transform=True): a PiecewiseCubicCDF on the identity half
+    (transforms.py:367-375, :417-473), fixture from the reference's classes (linear tails)."""
+    fx = load_golden('cubic_coupling_uncond_linear')
+    sd = golden_state_dict(fx)
+    K, Tb, Hn, L = int(fx['num_bins']), float(fx['tail_bound']), int(fx['hidden']), int(fx['n_layers'])
+    layers = [O.split_state_dict(sd, j) for j in range(L)]
+    assert 'unconditional_transform.unnorm_derivatives_left' in layers[0]
+    y, ld = O.composite([lambda v, s=s: O.cubic_coupling(s, v, K, 'linear', Tb, Hn, unconditional=True) for s in layers],
+                        T(fx['x']))
+    assert torch.equal(y, T(fx['y'])) and torch.equal(ld, T(fx['ld']))
+    xi, ldi = O.composite([lambda v, s=s: O.cubic_coupling(s, v, K, 'linear', Tb, Hn, inverse=True, unconditional=True)
+                           for s in reversed(layers)], y)
+    assert torch.equal(xi, T(fx['inv_of_y'])) and torch.equal(ldi, T(fx['inv_of_y_ld']))
+    l64 = [{k: (v.double() if v.is_floating_point() else v) for k, v in s_.items()} for s_ in layers]
+    y64, ld64 = O.composite([lambda v, s=s: O.cubic_coupling(s, v, K, 'linear', Tb, Hn, unconditional=True) for s in l64],
+                            T(fx['x']).double())
+    assert torch.equal(y64, T(fx['y64'])) and torch.equal(ld64, T(fx['ld64']))
