@@ -242,6 +242,17 @@ int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, const uint3
                                int64_t res_row_stride, float* y, int64_t y_row_stride, uint32_t* y_max, int64_t B,
                                int in, int out, int relu_in, int relu_out, int dtype, void* stream);
 
+/* Input-gradient GEMM in the split-operand modes: grad_x[B, in] = grad_y[B, out] @ (W * mask), zeroed where
+ * gate[B, in] <= 0 (gate NULL: no gating).  packed_wt / ktab_t / bias_zero = nf_linear_split_pack of the TRANSPOSED layer
+ * ([in, out], transposed mask, no bias).  Same kernel as nf_masked_linear_split_fwd; each tile's live K range is walked
+ * from its end down, which lines the column tiles of one row tile up on the same grad_y columns (one HBM fetch, the
+ * rest from L2).  grad_x_max (nullable): receives max |grad_x| like y_max.  (Replaces autograd through made.py:150-152.) */
+int nf_masked_linear_split_bwd_input(const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
+                                     const void* packed_wt, const int32_t* ktab_t, const float* bias_zero,
+                                     const float* gate, int64_t gate_row_stride, float* grad_x,
+                                     int64_t grad_x_row_stride, uint32_t* grad_x_max, int64_t B, int out, int in, int dtype,
+                                     void* stream);
+
 /* ---- coupling conditioner: the ResidualNet's hidden stack in one launch ------------------------------
  *      (replaces resnet.py:96-98 `initial_layer` + `blocks` and the `inputs[:, identity_features]` gather of
  *       transforms.py:88; BatchNorm in eval mode folded to scale/shift; no context, ReLU only) --------- */

@@ -111,6 +111,9 @@ _SIGNATURES = {
                                                       _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                       _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_maxabs': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    'nf_masked_linear_split_bwd_input': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                                    _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                                    _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_masked_linear_split_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                               _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
                                               _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -331,7 +334,8 @@ def maxabs(x):
     return slot
 
 
-def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, out=None, x_max=None, gate=None):
+def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, out=None, x_max=None, gate=None,
+                        reverse_k=False):
     """Split-operand hidden-layer GEMM.  The result is tagged (tag_max) with the slot holding max |out| so that a
     following split-operand launch needs no pass over it; x's own slot (`x_max`, else its valid tag) is used when
     present, else computed here."""
@@ -356,7 +360,14 @@ def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, ou
         x_max = maxabs(x)
     y_max = torch.empty(1, dtype=torch.int32, device=x.device)
 
+    if reverse_k and (relu_in or (residual is not None and gate is None) or relu_out == 1):
+        raise ValueError('reverse_k is the input-gradient launch: x = grad_y, pls = the transposed pack, optional gate')
+
     def launch():
+        if reverse_k:       # nf_masked_linear_split_bwd_input: the live K ranges walked from their (common) end down
+            return lib.nf_masked_linear_split_bwd_input(xp, xs, _ptr(x_max), pls.packed.data_ptr(), pls.ktab.data_ptr(),
+                                                        pls.bias.data_ptr(), rp, rs, yp, ys, y_max.data_ptr(), B,
+                                                        pls.inp, pls.out, pls.dtype, _stream())
         return lib.nf_masked_linear_split_fwd(xp, xs, _ptr(x_max), pls.packed.data_ptr(), pls.ktab.data_ptr(),
                                               pls.bias.data_ptr(), rp, rs, yp, ys, y_max.data_ptr(), B, pls.inp, pls.out,
                                               int(relu_in), int(relu_out), pls.dtype, _stream())

@@ -67,7 +67,7 @@ class MaskedLinearFn(torch.autograd.Function):
             if split_y:
                 # dX = dY @ (W * mask): the same split-operand kernel on the transposed layer, ReLU gate in its epilogue
                 gx = _lib.masked_linear_split(grad_y, layer._packed_linear_split_t(), x_max=gy_max,
-                                              gate=x if ctx.relu_in else None)
+                                              gate=x if ctx.relu_in else None, reverse_k=True)
             else:
                 gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if ctx.relu_in else None)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):

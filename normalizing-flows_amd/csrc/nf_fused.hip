@@ -74,6 +74,7 @@ struct FusedArgs {
     int vec_out;             // split GEMM: y / residual rows take 16-byte accesses (LDS-staged epilogue)
     int64_t m_tiles;
     int group_m;             // row tiles that share a weight tile back to back (L2 reuse)
+    int k_reverse;           // split GEMM: walk a tile's live K range from its end down (input-gradient launches)
     RqsConst c;
 };
 
@@ -584,6 +585,11 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
     const int lane = tid & 63, wc = tid >> 6;
     const int kt_begin = g.ktab[2 * tn];
     const int kt_end = min(g.ktab[2 * tn + 1], (g.K + XS - 1) / XS);
+    // The loop below counts LOGICAL steps 0 .. kn-1; KP() is the K step a logical step works on: the live range walked
+    // upwards, or - g.k_reverse, the input-gradient GEMM - from its end downwards (see nf_masked_linear_bwd_input)
+    const int kn = kt_end - kt_begin;
+    const bool krev = g.k_reverse != 0;
+#define KP(l_) (krev ? kt_end - 1 - (l_) : kt_begin + (l_))
 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -612,13 +618,13 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
     vec b[2][2][NT];                                   // [register set = step parity][j][term]
 #define X3_LOAD_A(s_, n_, kt_)                                                                        \
     {                                                                                                 \
-        if (PRE) rp[s_][n_] = *reinterpret_cast<const vec*>(app + (n_) * aplane + (kt_) * XS);        \
-        else if ((n_) < 2) ra[s_][(n_) & 1] = *reinterpret_cast<const float4*>(ap + min((kt_) * XS + ahalf * 8, g.K - 8) + 4 * (n_)); \
+        if (PRE) rp[s_][n_] = *reinterpret_cast<const vec*>(app + (n_) * aplane + KP(kt_) * XS);        \
+        else if ((n_) < 2) ra[s_][(n_) & 1] = *reinterpret_cast<const float4*>(ap + min(KP(kt_) * XS + ahalf * 8, g.K - 8) + 4 * (n_)); \
     }
 #define X3_LOAD_B(s_, j_, kt_)                                                                        \
     {                                                                                                 \
         _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_)                                             \
-            b[s_][j_][p_] = bp[(int64_t)(kt_) * BSTEP + ((j_) * NT + p_) * 64];                       \
+            b[s_][j_][p_] = bp[(int64_t)KP(kt_) * BSTEP + ((j_) * NT + p_) * 64];                       \
     }
 #define X3_STORE_A(s_, st_, kt_)                                                                      \
     {                                                                                                 \
@@ -627,7 +633,7 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
         if (PRE) {                                                                                    \
             _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) t_[p_] = rp[s_][p_];                    \
         } else {                                                                                      \
-            split_chunk<SP, RELU>(ra[s_][0], ra[s_][1], (kt_) * XS + ahalf * 8 < g.K, hs, t_);        \
+            split_chunk<SP, RELU>(ra[s_][0], ra[s_][1], KP(kt_) * XS + ahalf * 8 < g.K, hs, t_);        \
         }                                                                                             \
         _Pragma("unroll") for (int p_ = 0; p_ < NT; ++p_) *reinterpret_cast<vec*>(sa_ + p_ * XA) = t_[p_]; \
     }
@@ -638,8 +644,8 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
     {                                                                                                 \
         const elem* sA = stage0 + (par_) * XSTAGE;                                                    \
         elem* nxt = stage0 + ((par_) ^ 1) * XSTAGE;                                                   \
-        const int kt1 = min((kt_) + 1, kt_end - 1), kta = min((kt_) + 1 + NSET, kt_end - 1);          \
-        const int ktb = min((kt_) + 2, kt_end - 1);                                                   \
+        const int kt1 = min((kt_) + 1, kn - 1), kta = min((kt_) + 1 + NSET, kn - 1);          \
+        const int ktb = min((kt_) + 2, kn - 1);                                                   \
         vec a[4][NT];                                                                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
             _Pragma("unroll") for (int p = 0; p < NT; ++p)                                            \
@@ -662,27 +668,28 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
         __syncthreads();                                                                              \
     }
     // prologue: A step 0 into stage 0 and steps 1 .. NSET into the register sets; B steps 0 and 1
-    if (kt_begin < kt_end) {
+    if (kn > 0) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) X3_LOAD_A(0, n, kt_begin)
-        X3_LOAD_B(0, 0, kt_begin)
-        X3_LOAD_B(0, 1, kt_begin)
-        X3_STORE_A(0, stage0, kt_begin)
-        const int kb1 = min(kt_begin + 1, kt_end - 1);
+        for (int n = 0; n < NT; ++n) X3_LOAD_A(0, n, 0)
+        X3_LOAD_B(0, 0, 0)
+        X3_LOAD_B(0, 1, 0)
+        X3_STORE_A(0, stage0, 0)
+        const int kb1 = min(1, kn - 1);
         X3_LOAD_B(1, 0, kb1)
         X3_LOAD_B(1, 1, kb1)
 #pragma unroll
         for (int q = 0; q < NSET; ++q) {
-            const int kq = min(kt_begin + 1 + q, kt_end - 1);
+            const int kq = min(1 + q, kn - 1);
 #pragma unroll
             for (int n = 0; n < NT; ++n) X3_LOAD_A(q, n, kq)
         }
     }
     __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+    for (int kt = 0; kt < kn; kt += 2) {
         X3_STEP(0, 0, kt)
-        if (kt + 1 < kt_end) X3_STEP(NSET - 1, 1, kt + 1)
+        if (kt + 1 < kn) X3_STEP(NSET - 1, 1, kt + 1)
     }
+#undef KP
 #undef X3_STEP
 #undef X3_STORE_A
 #undef X3_LOAD_B
@@ -1816,7 +1823,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     FusedArgs g;
     g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
-    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max; g.vec_out = 0;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max; g.vec_out = 0; g.k_reverse = 0;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
@@ -1977,11 +1984,11 @@ static int launch_linear_split(const FusedArgs& g, int grid, size_t lds, int rel
     return nf_launch_status();
 }
 
-extern "C" int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, const uint32_t* x_max,
-                                          const void* packed_w, const int32_t* ktab, const float* bias_packed,
-                                          const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride,
-                                          uint32_t* y_max, int64_t B, int in, int out, int relu_in, int relu_out,
-                                          int dtype, void* stream) {
+static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                             const void* packed_w, const int32_t* ktab, const float* bias_packed,
+                             const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride,
+                             uint32_t* y_max, int64_t B, int in, int out, int relu_in, int relu_out,
+                             int dtype, int k_reverse, void* stream) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (!split_terms(dtype)) return NF_ERR_DTYPE;
     hipStream_t s = (hipStream_t)stream;
@@ -1998,7 +2005,7 @@ extern "C" int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, 
     const int nt = nf_linear_split_tiles(out);
     g.h = x; g.ldh = x_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
     g.y = y; g.ldy = y_row_stride; g.M = B; g.K = in; g.N = out; g.n_tiles = nt; g.tn0 = 0;
-    g.m_tiles = (B + XM - 1) / XM; g.group_m = 8;
+    g.m_tiles = (B + XM - 1) / XM; g.group_m = 8; g.k_reverse = k_reverse;
     g.wmax = (const unsigned*)(ktab + 2 * nt); g.hmax = (const unsigned*)x_max;
     g.residual = residual; g.ldr = res_row_stride; g.relu_out = relu_out; g.out_max = (unsigned*)y_max;
     const int64_t grid = g.m_tiles * nt;
@@ -2051,6 +2058,28 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
     else if (tw == 2) hipLaunchKernelGGL((wgrad_split_kernel<2, SplitF16x1>), gr, bl, lds, s, g);
     else hipLaunchKernelGGL((wgrad_split_kernel<1, SplitF16x1>), gr, bl, lds, s, g);
     return nf_launch_status();
+}
+
+extern "C" int nf_masked_linear_split_fwd(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                          const void* packed_w, const int32_t* ktab, const float* bias_packed,
+                                          const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride,
+                                          uint32_t* y_max, int64_t B, int in, int out, int relu_in, int relu_out,
+                                          int dtype, void* stream) {
+    return linear_split_impl(x, x_row_stride, x_max, packed_w, ktab, bias_packed, residual, res_row_stride, y,
+                             y_row_stride, y_max, B, in, out, relu_in, relu_out, dtype, 0, stream);
+}
+
+// Input-gradient GEMM on split operands: nf_masked_linear_split_fwd on the TRANSPOSED pack (x = grad_y, `gate` = the
+// forward input whose sign gates the result, NULL for none), with each tile's live K range walked from its END down:
+// under MADE's transposed masks the column tiles' ranges share their end, so the column tiles of one row tile -
+// scheduled back to back on one XCD - pass the same grad_y columns together and all but one find them in L2.
+extern "C" int nf_masked_linear_split_bwd_input(const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
+                                                const void* packed_wt, const int32_t* ktab_t, const float* bias_zero,
+                                                const float* gate, int64_t gate_row_stride, float* grad_x,
+                                                int64_t grad_x_row_stride, uint32_t* grad_x_max, int64_t B, int out, int in,
+                                                int dtype, void* stream) {
+    return linear_split_impl(grad_y, grad_y_row_stride, grad_y_max, packed_wt, ktab_t, bias_zero, gate, gate_row_stride,
+                             grad_x, grad_x_row_stride, grad_x_max, B, out, in, 0, gate ? 2 : 0, dtype, 1, stream);
 }
 
 extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, const uint32_t* x_max,

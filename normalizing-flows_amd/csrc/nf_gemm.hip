@@ -48,6 +48,7 @@ struct GemmArgs {
     int64_t m_tiles;
     int vec_a;               // x rows 16-byte aligned and K % 4 == 0
     int vec_out;             // y / residual / gate / bias take 16-byte accesses (LDS-staged epilogue)
+    int k_reverse;           // walk the live K range from its END down (see nf_masked_linear_bwd_input)
 };
 
 // 16-byte epilogue of the 128 x 128 block kernels: each wave drops 16 rows x its 64 columns of accumulators into LDS
@@ -212,8 +213,10 @@ __global__ __launch_bounds__(GT, 2) void masked_linear_f32_kernel(const GemmArgs
         load_one<VEC_A>(g, ar3, br3, k_, kt_, a3, b3);                    \
     } while (0)
 
-    if (kt_begin < kt_end) NF_LOAD_TILE(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int kn = kt_end - kt_begin, kdir = g.k_reverse ? -1 : 1, kfirst = g.k_reverse ? kt_end - 1 : kt_begin;
+    if (kn > 0) NF_LOAD_TILE(kfirst);
+    for (int ki = 0; ki < kn; ++ki) {
+        const int kt = kfirst + kdir * ki;
         __syncthreads();             // everyone done reading the previous tile
         {
             const int k = kt * BK + skc;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(GT, 2) void masked_linear_f32_kernel(const GemmArgs
             store_one<IN_AFFINE, RELU_IN>(g, as0 + 96 * LDS_LD, bs0 + 96 * LDS_LD, k, sc, sh, a3, b3);
         }
         __syncthreads();
-        NF_LOAD_TILE(min(kt + 1, kt_end - 1));   // in flight under the MFMAs below (the last one is a re-read)
+        NF_LOAD_TILE(ki + 1 < kn ? kt + kdir : kt);   // in flight under the MFMAs below (the last one is a re-read)
         __builtin_amdgcn_sched_barrier(0);       // keep the prefetch issue ABOVE the MFMAs
 
         const int frow = lane & 31, fk = (lane >> 5) * 4;
@@ -376,8 +379,10 @@ __global__ __launch_bounds__(GT, 2) void masked_linear_bf16_kernel(const GemmArg
         load_one16<VEC_A>(g, ar3, br3, k_, kt_, a3l, a3h, b3);            \
     } while (0)
 
-    if (kt_begin < kt_end) NF_LOAD_TILE16(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int kn = kt_end - kt_begin, kdir = g.k_reverse ? -1 : 1, kfirst = g.k_reverse ? kt_end - 1 : kt_begin;
+    if (kn > 0) NF_LOAD_TILE16(kfirst);
+    for (int ki = 0; ki < kn; ++ki) {
+        const int kt = kfirst + kdir * ki;
         __syncthreads();
         {
             const int k = kt * BK16 + skc;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(GT, 2) void masked_linear_bf16_kernel(const GemmArg
             store_one16<IN_AFFINE, RELU_IN>(g, as0 + 96 * LDS_LD16, bs0 + 96 * LDS_LD16, k, sc, sh, a3l, a3h, b3);
         }
         __syncthreads();
-        NF_LOAD_TILE16(min(kt + 1, kt_end - 1));
+        NF_LOAD_TILE16(ki + 1 < kn ? kt + kdir : kt);
         __builtin_amdgcn_sched_barrier(0);
 
         const int frow = lane & 31, fk = (lane >> 5) * 8;
@@ -707,7 +712,7 @@ static int linear_impl(const float* x, int64_t x_row_stride, const void* packed_
                        const float* bias, const float* residual, int64_t residual_row_stride, const float* in_scale,
                        const float* in_shift, const float* gate, int64_t gate_row_stride, float* y,
                        int64_t y_row_stride, int64_t B, int in, int out, int relu_in, int relu_out, int dtype,
-                       int n_tile_begin, int n_tile_count, void* stream) {
+                       int n_tile_begin, int n_tile_count, void* stream, int k_reverse = 0) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (B == 0) return NF_OK;
     if (!x || !packed_w || !ktab || !y) return NF_ERR_NULL;
@@ -727,6 +732,7 @@ static int linear_impl(const float* x, int64_t x_row_stride, const void* packed_
     const int vec = dtype == NF_DTYPE_BF16 ? 8 : 4;      // floats per staged chunk
     g.vec_a = (in % vec == 0) && (x_row_stride % 4 == 0) && (((uintptr_t)x & 15) == 0);
     auto a16 = [](const void* p, int64_t ld) { return p == nullptr || (ld % 4 == 0 && ((uintptr_t)p & 15) == 0); };
+    g.k_reverse = k_reverse;
     g.vec_out = out % 4 == 0 && a16(y, y_row_stride) && a16(bias, 0) && a16(residual, residual_row_stride) &&
                 a16(gate, gate_row_stride);
     const int64_t grid = g.m_tiles * g.n_tiles;
@@ -778,7 +784,11 @@ extern "C" int nf_masked_linear_bwd_input(const float* grad_y, int64_t grad_y_ro
     if (gate && gate_row_stride < in) return NF_ERR_LAYOUT;
     return linear_impl(grad_y, grad_y_row_stride, packed_wt, ktab_t, nullptr, nullptr, 0, nullptr, nullptr, gate,
                        gate_row_stride, grad_x, grad_x_row_stride, B, out, in, 0, 0, dtype, 0,
-                       in > 0 ? n_tiles_of(in) : 0, stream);
+                       in > 0 ? n_tiles_of(in) : 0, stream, 1);
+    // (k_reverse = 1: under MADE's transposed masks the live K ranges of the column tiles share their END, not their
+    //  start; walked downwards, the column tiles of one row tile - scheduled back to back on one XCD - pass the same
+    //  grad_y columns at the same time and all but one of them find them in L2.  The final layer's 2.4 GB of
+    //  grad_params were otherwise fetched once per column tile.)
 }
 
 extern "C" int nf_masked_linear_fwd(const float* x, int64_t x_row_stride, const void* packed_w, const int32_t* ktab,
