@@ -51,6 +51,10 @@ def main():
         ms = timed(lambda: _lib.masked_linear_split_bwd_weight(x, gy, mask, ktab, True, x_max=xm, grad_y_max=gm))
         res['split_ms'] = round(ms, 3)
         res['split_unmasked_tflops'] = round(flop / ms / 1e9, 1)
+    if a.only in ('', 'half'):
+        ms = timed(lambda: _lib.masked_linear_split_bwd_weight(x, gy, mask, ktab, True, x_max=xm, grad_y_max=gm, terms=1))
+        res['half_ms'] = round(ms, 3)
+        res['half_unmasked_tflops'] = round(flop / ms / 1e9, 1)
     if a.only in ('', 'f32'):
         ms = timed(lambda: _lib.masked_linear_bwd_weight(x, gy, mask, ktab, True))
         res['f32_ms'] = round(ms, 3)

@@ -1173,6 +1173,235 @@ __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const Wgr
         }
 }
 
+// ---- weight gradient, one fp16 term per operand, transposed LDS reads (bf16 training mode) ---------------------
+// Same product as wgrad_split_kernel<2, SplitF16x1> (8 waves, 32 batch rows per step, batch splits with fp32
+// atomics, masked tiles skipped), different tile and operand path: the MFMA wants, per lane, 8 consecutive BATCH
+// rows of one column, while grad_y / x are stored batch-major.  wgrad_split_kernel fetches that shape directly - 24
+// four-byte loads per lane and step, which is what bounded it (2.1 ms on the final layer).  Here a chunk is fetched
+// the way it lies in memory - 16-byte loads along a row, a wave takes 1 KB contiguous -, scaled, converted and stored
+// ROW-major in LDS (8 bytes per load), and the operands come out column-major through gfx950's transposing read
+// `ds_read_b64_tr_b16` (per 16 lanes: a 4-row x 16-column block, delivered one column per lane).  LDS images are
+// [32 batch rows][128 columns] fp16 with 256-byte rows and the 16-byte chunks of a row XOR-swizzled by
+// ((row & 3) << 2) | ((row >> 2) & 3): conflict-free for these reads (cdna_hip_programming.md T10, layout (b)).
+// Tile: 128 output rows x WT_K = 256 input columns of grad_W per workgroup (8 waves of 64 x 64).  With 512 columns a
+// grad_y chunk would be fetched once for the whole input width of this model's wide layers, but 128 accumulator
+// registers leave no room for chunks in flight (measured: spills, 1.7-11 ms); with 256 the two K tiles of an output
+// tile are neighbours on one XCD and the second finds grad_y in L2.  The x chunk is the same for every workgroup of a
+// batch split and stays in L2.  A buffer = grad_y columns 0..127 + x columns 0..255 as two images (3 x 8 KB), double
+// buffered: 48 KB.
+constexpr int WT_IMG = 32 * 256;                   // bytes of one image
+constexpr int WT_N = 128, WT_K = 256;
+__device__ __forceinline__ int wt_off(int row, int ch) {     // byte offset of 16-byte chunk ch (0..15) of a row
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s4* lds_s4;
+    constexpr int NIMG = 1 + WT_K / 128;             // images per buffer: grad_y + x
+    constexpr int XL = WT_K / 64;                    // 16-byte x loads per thread and chunk
+    constexpr int XG = WT_K / 4;                     // four-column groups of an x row
+    constexpr int NJ = WT_K / 128;                   // 32-column blocks of a wave along the input width
+    extern __shared__ __attribute__((aligned(16))) char wt_lds[];       // [2 buffers][NIMG images][8 KB]
+    const int slot = blockIdx.x >> 3;
+    const int64_t w = ((int64_t)(slot / g.group) * 8 + (blockIdx.x & 7)) * g.group + slot % g.group;
+    if (w >= (int64_t)g.nt * g.kt * g.splits) return;
+    const int tk = (int)(w % g.kt), tn = g.nt - 1 - (int)((w / g.kt) % g.nt), split = (int)(w / ((int64_t)g.kt * g.nt));
+    const int n0 = tn * WT_N, k0 = tk * WT_K;
+    const bool do_bias = g.gb != nullptr && tk == 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;         // wave tile: 64 (out) x WT_K / 4 (in)
+    // live K range of this tile's 128 output rows (forward table, 32-wide units): a wave whose input columns lie
+    // outside it has only masked weights to produce
+    int kb = 0, ke = g.in;
+    if (g.ktab) { kb = g.ktab[2 * tn] * 32; ke = g.ktab[2 * tn + 1] * 32; }
+    const int cw = wc * (WT_K / 4), kw0 = k0 + cw;
+    const bool live = kw0 < min(ke, g.in) && kw0 + WT_K / 4 > kb;
+    const bool any_live = k0 < min(ke, g.in) && k0 + WT_K > kb;
+    if (!any_live && !do_bias) return;
+    const int64_t per = ((g.M + g.splits - 1) / g.splits + 6 * WSB - 1) / (6 * WSB) * (6 * WSB);
+    const int64_t b_begin = (int64_t)split * per, b_end = min(g.M, b_begin + per);
+    if (b_begin >= b_end) return;
+    float sy, iy, sx, ix;
+    pow2_pair(*g.gy_max, sy, iy);
+    pow2_pair(*g.x_max, sx, ix);
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fetch map: grad_y chunk = 32 rows x 32 four-column groups, thread = group (tid & 31) x rows (tid >> 5) + 16 e;
+    // x chunk = 32 rows x XG groups, thread = group (tid % XG) x rows (tid / XG) + (512 / XG) e.  Columns past the matrix
+    // edge are clamped (they only reach accumulator entries that are never stored), rows past the batch end are clamped
+    // and scaled by 0.  Every load is unconditional: a load under a branch makes hipcc wait vmcnt(0) at each use.
+    const int ycg = tid & 31, yr0 = tid >> 5, xcg = tid % XG, xr0 = tid / XG;
+    const float* ycol = g.gy + min(n0 + 4 * ycg, g.out - 4);
+    const float* xcol = g.x + min(k0 + 4 * xcg, g.in - 4);
+    // grad_y comes from HBM: three chunks of it in flight; x is the same for every workgroup of a batch split (L2): two
+    float4 cy[3][2], cx[2][XL];
+    auto load_y = [&](int c, int64_t b0) {
+#ifndef NF_WT_KO_LOADS
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            cy[c][e] = *reinterpret_cast<const float4*>(ycol + min(b0 + yr0 + 16 * e, b_end - 1) * g.ldgy);
+#endif
+    };
+    auto load_x = [&](int c, int64_t b0) {
+#ifndef NF_WT_KO_LOADS
+#pragma unroll
+        for (int e = 0; e < XL; ++e)
+            cx[c][e] = *reinterpret_cast<const float4*>(xcol + min(b0 + xr0 + (512 / XG) * e, b_end - 1) * g.ldx);
+#endif
+    };
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};            // in grad_y's scaled units: this thread's four columns
+    auto convert = [&](int yc, int xc, int64_t b0, int buf) {
+#ifndef NF_WT_KO_CONV
+        char* base = wt_lds + buf * NIMG * WT_IMG;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = yr0 + 16 * e;
+            const float sc = b0 + r < b_end ? sy : 0.f;
+            const float v0 = cy[yc][e].x * sc, v1 = cy[yc][e].y * sc, v2 = cy[yc][e].z * sc, v3 = cy[yc][e].w * sc;
+            bsum[0] += v0; bsum[1] += v1; bsum[2] += v2; bsum[3] += v3;
+            h4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+            *reinterpret_cast<h4*>(base + wt_off(r, ycg >> 1) + 8 * (ycg & 1)) = hv;
+        }
+#pragma unroll
+        for (int e = 0; e < XL; ++e) {
+            const int r = xr0 + (512 / XG) * e;
+            float v0 = cx[xc][e].x, v1 = cx[xc][e].y, v2 = cx[xc][e].z, v3 = cx[xc][e].w;
+            if (g.relu_in) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            h4 hv = {(_Float16)(v0 * sx), (_Float16)(v1 * sx), (_Float16)(v2 * sx), (_Float16)(v3 * sx)};
+            *reinterpret_cast<h4*>(base + (1 + (xcg >> 5)) * WT_IMG + wt_off(r, (xcg & 31) >> 1) + 8 * (xcg & 1)) = hv;
+        }
+#endif
+    };
+    // transposed operand reads: group gq = lane >> 4 of 16 lanes, lane 4q + p of it addresses row q, columns 4p..4p+3 of
+    // its block and receives column (lane & 15); block = rows 16 ks + 8 (gq >> 1) + 4 t .. + 3, columns base + 16 (gq & 1)
+    const int gq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    int aoff[2][2], boff[NJ][2];                     // [i or j][t]: byte offsets inside a buffer, ks = 0
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = 8 * (gq >> 1) + 4 * t + tq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            aoff[i][t] = wt_off(row, (64 * wr + 32 * i + 16 * (gq & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = cw + 32 * j + 16 * (gq & 1);             // of the x chunk's WT_K columns
+            boff[j][t] = (1 + col / 128) * WT_IMG + wt_off(row, (col % 128) / 8 + (tp >> 1)) + 8 * (tp & 1);
+        }
+    }
+    auto rd = [&](const char* base, int off) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base + off));
+    };
+    auto mma = [&](int buf) {
+#ifndef NF_WT_KO_MMA
+        if (!live) return;                           // wave-uniform
+        const char* base = wt_lds + buf * NIMG * WT_IMG;
+#pragma unroll
+        for (int ks = 0; ks < WSB / 16; ++ks) {
+            f16x8 a[2], b[NJ];
+            // (rows + 16 ks: 4096 bytes further, the swizzle does not involve that bit)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const s4 lo = rd(base, aoff[i][0] + 4096 * ks), hi = rd(base, aoff[i][1] + 4096 * ks);
+                const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                a[i] = __builtin_bit_cast(f16x8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const s4 lo = rd(base, boff[j][0] + 4096 * ks), hi = rd(base, boff[j][1] + 4096 * ks);
+                const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                b[j] = __builtin_bit_cast(f16x8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+#endif
+    };
+    // the step barrier orders LDS traffic only: __syncthreads() would also drain vmcnt, i.e. wait out the chunks
+    // requested steps ahead on purpose
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // Waves w and w + 4 share a SIMD and take the two halves of a step - the MFMAs of chunk s (reads buffer s & 1) and
+    // the conversion of chunk s + 1 (writes the other buffer) - in opposite order: one's vector-ALU / LDS work runs
+    // under the other's MFMAs instead of all eight waves queueing on the same pipe in lockstep.
+    const bool mma_first = __builtin_amdgcn_readfirstlane(wave >> 2) != 0;
+    // step s (chunk s = rows b_begin + 32 s ..): convert chunk s + 1 (grad_y set (s + 1) % 3, x set (s + 1) & 1) into
+    // LDS buffer (s + 1) & 1 - its last readers passed the previous barrier -, request x chunk s + 3 and then grad_y
+    // chunk s + 4 into the sets just freed (x first: loads return in order, and the next step's wait for its x must
+    // not include a fresh HBM fetch), and run the MFMAs of chunk s.  Unrolled by 6: every set / buffer index constant.
+    // No exit inside the six steps (an early exit gives the loop header a second predecessor whose loads were issued
+    // one step ago, and hipcc then waits for ALL loads in step 0): steps past the batch end multiply zeros.
+    load_y(0, b_begin);
+    load_x(0, b_begin);
+    load_y(1, b_begin + WSB);
+    load_x(1, b_begin + WSB);
+    load_y(2, b_begin + 2 * WSB);
+    convert(0, 0, b_begin, 0);
+    load_x(0, b_begin + 2 * WSB);
+    load_y(0, b_begin + 3 * WSB);
+    __syncthreads();
+#define WT_STEP(S_)                                                                       \
+    {                                                                                     \
+        const int64_t bs_ = b0 + (S_) * WSB;                                              \
+        if (mma_first) { mma((S_) & 1); __builtin_amdgcn_sched_barrier(0); }              \
+        convert(((S_) + 1) % 3, ((S_) + 1) & 1, bs_ + WSB, ((S_) + 1) & 1);               \
+        load_x(((S_) + 1) & 1, bs_ + 3 * WSB);                                            \
+        load_y(((S_) + 1) % 3, bs_ + 4 * WSB);                                            \
+        if (!mma_first) { __builtin_amdgcn_sched_barrier(0); mma((S_) & 1); }             \
+        lds_barrier();                                                                    \
+    }
+    for (int64_t b0 = b_begin; b0 < b_end; b0 += 6 * WSB) {
+        WT_STEP(0) WT_STEP(1) WT_STEP(2) WT_STEP(3) WT_STEP(4) WT_STEP(5)
+    }
+#undef WT_STEP
+    if (do_bias) {           // the 16 threads that share a column group add up through LDS (fixed order), one atomic each
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(wt_lds);           // [16][128]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[yr0 * 128 + 4 * ycg + q] = bsum[q];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < g.out) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += red[q * 128 + tid];
+            atomicAdd(&g.gb[n0 + tid], s * iy);
+        }
+    }
+#ifdef NF_WT_KO_EPI
+    if (acc[0][0][0] != 12345.f) return;
+#endif
+    if (!live) return;
+    const float oscale = iy * ix;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = kw0 + j * 32 + (lane & 31);
+            if (k >= g.in) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n >= g.out) continue;
+                const int64_t idx = (int64_t)n * g.in + k;
+                float v = acc[i][j][r] * oscale;
+                if (g.mask) v *= g.mask[idx];
+                if (g.splits > 1) atomicAdd(&g.gw[idx], v);
+                else g.gw[idx] += v;
+            }
+        }
+}
+
 // packed[tile][step][wave 0..3][j 0..1][term][lane 0..63][8]: the 8 elements lane `lane` feeds to the MFMA as
 // the B operand of column block j of wave `wave` - row = wave*64 + j*32 + (lane & 31) of the tile,
 // k = step*16 + (lane >> 5)*8 + e - i.e. term t of W[n][k] * mask * fold (* the scale slot's power of two)
@@ -2053,6 +2282,26 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
     const size_t lds = (size_t)2 * terms * (128 * tw + 128) * WSLD * sizeof(_Float16);   // 2 buffers x terms
     const dim3 gr((unsigned)blocks), bl(256 * tw);
     hipStream_t s = (hipStream_t)stream;
+    // one term, wide layer, everything 16-byte addressable: the transposed-read kernel (row-wise 16-byte fetches)
+    if (terms == 1 && tw == 2 && in % 4 == 0 && out % 4 == 0 && in >= 4 && out >= 4 && x_row_stride % 4 == 0 &&
+        grad_y_row_stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad_y) & 15) == 0) {
+        g.nt = (out + WT_N - 1) / WT_N;
+        g.kt = (in + WT_K - 1) / WT_K;
+        // batch splits: whole rounds of 256 workgroups (one per CU), about five of them
+        int64_t sp = (5 * 256 + (int64_t)g.nt * g.kt / 2) / ((int64_t)g.nt * g.kt);
+        if (sp < 1) sp = 1;
+        if (sp > max_splits) sp = max_splits;
+        g.splits = (int)sp;
+        g.group = g.kt * (32 / g.kt < 1 ? 1 : (32 / g.kt < g.nt ? 32 / g.kt : g.nt));
+        const int64_t wk = (int64_t)g.nt * g.kt * sp;
+        const int64_t gd = (wk + g.group - 1) / g.group * g.group;
+        const int64_t bk = (gd / g.group + 7) / 8 * 8 * g.group;
+        if (bk > 0x7fffffff) return NF_ERR_SHAPE;
+        static unsigned long long tr_cap = 0;
+        if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel, &tr_cap)) return e;
+        hipLaunchKernelGGL(wgrad_tr_kernel, dim3((unsigned)bk), dim3(512), 2 * (1 + WT_K / 128) * WT_IMG, s, g);
+        return nf_launch_status();
+    }
     if (terms == 2 && tw == 2) hipLaunchKernelGGL((wgrad_split_kernel<2, SplitF16x2>), gr, bl, lds, s, g);
     else if (terms == 2) hipLaunchKernelGGL((wgrad_split_kernel<1, SplitF16x2>), gr, bl, lds, s, g);
     else if (tw == 2) hipLaunchKernelGGL((wgrad_split_kernel<2, SplitF16x1>), gr, bl, lds, s, g);

@@ -2320,3 +2320,26 @@ def test_cubic_coupling_with_unconditional_transform_golden(nf):
     wa, wl = O.cubic_cdf(csd, z.cpu().double(), None, 1.0)
     _assert_close_noisy(a, wa, wa.float())
     assert torch.quantile((b - z).abs().reshape(-1), 0.99).item() < 1e-3
+
+
+@pytest.mark.parametrize('shape', [(1000, 132, 2052, True), (4096, 512, 4600, False), (70, 8, 2048, True)])
+def test_half_precision_weight_gradient_transposed_read_kernel(nf, shape):
+    """nf_masked_linear_half_bwd_weight on wide layers (>= 2048 outputs: wgrad_tr_kernel, row-wise fetches + transposing
+    LDS reads) against the fp64 product: ragged batch / widths, ReLU on x, mask, bias gradient; and against the
+    4-byte-fetch kernel it replaces (same operands, same fp16 rounding: equal up to fp32 summation order)."""
+    B, inp, out, relu = shape
+    g = torch.Generator(device='cuda').manual_seed(B + out)
+    x = torch.randn(B, inp, device='cuda', generator=g)
+    gy = torch.randn(B, out, device='cuda', generator=g) * 0.01
+    mask = (torch.rand(out, inp, device='cuda', generator=g) > 0.3).float()
+    gw, gb = nf._lib.masked_linear_split_bwd_weight(x, gy, mask, None, relu, want_bias=True, terms=1)
+    xa = torch.relu(x) if relu else x
+    want_w = (gy.double().t() @ xa.double()) * mask.double()
+    want_b = gy.double().sum(0)
+    assert _nerr(gw, want_w) < 2e-3, _nerr(gw, want_w)          # one fp16 term per operand: 2^-11 relative per product
+    assert _nerr(gb, want_b) < 2e-3
+    # the same operands through the strided-fetch kernel (row views break the 16-byte test of the new one)
+    xs = torch.zeros(B, inp + 1, device='cuda')[:, :inp]
+    xs.copy_(x)
+    gw2, gb2 = nf._lib.masked_linear_split_bwd_weight(xs, gy, mask, None, relu, want_bias=True, terms=1)
+    assert _nerr(gw, gw2.double()) < 1e-5 and _nerr(gb, gb2.double()) < 1e-5
