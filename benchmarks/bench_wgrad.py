@@ -37,8 +37,11 @@ def main():
     flop = 2.0 * B * I * O * mask.mean().item()
 
     def timed(fn):
-        fn()
-        torch.cuda.synchronize()
+        import time
+        t0 = time.time()
+        while time.time() - t0 < 0.5:        # clocks ramp up over the first few hundred ms of a fresh process
+            fn()
+            torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(a.reps):
