@@ -18,8 +18,8 @@ from . import _lib
 
 
 def _split_mode(x, width):
-    """True when the matrix mode is one of the split-operand ones (fp32 contract on the fp16 / bf16 matrix pipe)
-    and the split GEMM kernel takes this operand; then forward and input-gradient GEMMs run on it too."""
+    """True when the matrix mode runs its hidden-layer GEMMs on the split-operand kernel (the split modes, and bf16
+    as its one-term flavour) and that kernel takes this operand; then forward and input-gradient GEMMs run on it."""
     from . import made
     return made.get_matmul_dtype() in made._SPLIT_MODES and _lib.split_gemm_supported(x, width)
 
@@ -74,15 +74,15 @@ class MaskedLinearFn(torch.autograd.Function):
             if _bf16_mode() and _lib.split_gemm_supported(grad_y, layer.out_features):
                 # bf16 mode: one scaled fp16 term per operand (11 bits against bf16's 8, same MFMA rate)
                 gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
-                                                             layer._packed_linear().ktab, ctx.relu_in,
-                                                             want_bias=ctx.has_bias, grad_y_max=gy_max, terms=1)
+                                                             layer._wgrad_ktab(), ctx.relu_in, want_bias=ctx.has_bias,
+                                                             x_max=ctx.x_max, grad_y_max=gy_max, terms=1)
             elif split_y and ctx.x_max is not None and _f16x2_mode():
                 gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
-                                                             layer._packed_linear().ktab, ctx.relu_in,
+                                                             layer._wgrad_ktab(), ctx.relu_in,
                                                              want_bias=ctx.has_bias, x_max=ctx.x_max, grad_y_max=gy_max)
             else:
                 gw, gb = _lib.masked_linear_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
-                                                       layer._packed_linear().ktab, ctx.relu_in, want_bias=ctx.has_bias)
+                                                       layer._wgrad_ktab(), ctx.relu_in, want_bias=ctx.has_bias)
         gres = grad_y if ctx.has_residual else None
         return gx, gw, gb, gres, None, None
 

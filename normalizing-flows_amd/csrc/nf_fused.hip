@@ -542,6 +542,19 @@ struct SplitF16x1 {
     }
 };
 
+// One bf16 term per operand, unscaled: the plain bf16-MFMA product of the 2e-2 mode (forward and input-gradient GEMMs)
+// on the split kernels' tiling and K loop.
+struct SplitBf16x1 {
+    static constexpr int NT = 1;
+    static constexpr bool SCALED = false;
+    typedef __bf16 elem;
+    typedef bf16x8 vec;
+    static __device__ __forceinline__ void split1(float a, elem (&t)[NT]) { t[0] = (__bf16)a; }
+    static __device__ __forceinline__ void fma_tile(f32x16& acc, const vec (&a)[NT], const vec (&b)[NT]) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    }
+};
+
 // s = 2^e with m * 2^e in [2^13, 2^14) for the float whose bit pattern is `bits` (0 / denormal: s = 1); inv = 2^-e
 __device__ __forceinline__ void pow2_pair(unsigned bits, float& s, float& inv) {
     const int ex = (int)((bits >> 23) & 0xff) - 126;          // m = f * 2^ex, f in [0.5, 1)
@@ -612,7 +625,8 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
     const int roff = frow * XLD + (((lane >> 5) ^ ((frow >> 3) & 1)) * 8);
     // NSET register sets of staged A: with two (the two-term flavour has the registers for it) a load issued
     // during step k is consumed during step k+2 - a 768-cycle step alone does not cover an L2 round trip
-    constexpr int NSET = NT == 2 ? 2 : 1;
+    constexpr int NSET = NT <= 2 ? 2 : 1;
+    constexpr int NLA = PRE ? NT : 2;                  // A loads per step: a vector per term plane, or the two fp32 halves
     float4 ra[NSET][2];
     vec rp[NSET][NT];
     vec b[2][2][NT];                                   // [register set = step parity][j][term]
@@ -655,7 +669,7 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
                 const int grp = j * 4 + i;                                                            \
                 if (grp == 1 && !NF_KO_STORE) X3_STORE_A(s_, nxt, kt1)                                \
                 if (!NF_KO_LOADS) {                                                                   \
-                    _Pragma("unroll") for (int n = 0; n < NT; ++n)                                    \
+                    _Pragma("unroll") for (int n = 0; n < NLA; ++n)                                   \
                         if (grp == 2 + n) X3_LOAD_A(s_, n, kta)                                       \
                     if (grp == 5) X3_LOAD_B(par_, 0, ktb)                                             \
                 }                                                                                     \
@@ -670,7 +684,7 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
     // prologue: A step 0 into stage 0 and steps 1 .. NSET into the register sets; B steps 0 and 1
     if (kn > 0) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) X3_LOAD_A(0, n, 0)
+        for (int n = 0; n < NLA; ++n) X3_LOAD_A(0, n, 0)
         X3_LOAD_B(0, 0, 0)
         X3_LOAD_B(0, 1, 0)
         X3_STORE_A(0, stage0, 0)
@@ -681,7 +695,7 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
         for (int q = 0; q < NSET; ++q) {
             const int kq = min(1 + q, kn - 1);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) X3_LOAD_A(q, n, kq)
+            for (int n = 0; n < NLA; ++n) X3_LOAD_A(q, n, kq)
         }
     }
     __syncthreads();
@@ -2152,17 +2166,20 @@ extern "C" int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void*
 // ---- split-operand hidden-layer GEMM ------------------------------------------------------------------
 extern "C" int nf_linear_split_tiles(int out) { return out <= 0 ? 0 : (out + FN - 1) / FN; }
 
+// terms per operand of the hidden-layer GEMM: the split modes' two / three, or NF_DTYPE_BF16's single bf16 term
+static inline int linear_terms(int dtype) { return dtype == NF_DTYPE_BF16 ? 1 : split_terms(dtype); }
+
 extern "C" size_t nf_linear_split_packed_bytes(int out, int in, int dtype) {
-    if (out <= 0 || in <= 0 || !split_terms(dtype)) return 0;
-    return (size_t)nf_linear_split_tiles(out) * FN * kpad_of(in) * 2 * split_terms(dtype);
+    if (out <= 0 || in <= 0 || !linear_terms(dtype)) return 0;
+    return (size_t)nf_linear_split_tiles(out) * FN * kpad_of(in) * 2 * linear_terms(dtype);
 }
 
 static int linear_split_pack_impl(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
                                   void* packed, int32_t* ktab, float* bias_packed, bool table, void* stream) {
     if (!W || !packed || !ktab || !bias_packed) return NF_ERR_NULL;
     if (out <= 0 || in <= 0) return NF_ERR_SHAPE;
-    if (!split_terms(dtype)) return NF_ERR_DTYPE;
-    const int nt = nf_linear_split_tiles(out), kpad = kpad_of(in), terms = split_terms(dtype);
+    if (!linear_terms(dtype)) return NF_ERR_DTYPE;
+    const int nt = nf_linear_split_tiles(out), kpad = kpad_of(in), terms = linear_terms(dtype);
     const int64_t total = (int64_t)terms * nt * FN * kpad;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;
@@ -2175,6 +2192,9 @@ static int linear_split_pack_impl(const float* W, const float* mask, const float
         hipLaunchKernelGGL(maxabs_kernel, dim3(mgrid), dim3(256), 0, s, W, mask, nw, 1, in, 0, 1.0f, slot);
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitF16x2>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
                            kpad, total, 1, 0, 1.0f, (const unsigned*)slot, (_Float16*)packed, bias_packed);
+    } else if (dtype == NF_DTYPE_BF16) {
+        hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x1>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
+                           kpad, total, 1, 0, 1.0f, (const unsigned*)nullptr, (__bf16*)packed, bias_packed);
     } else {
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x3>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
                            kpad, total, 1, 0, 1.0f, (const unsigned*)nullptr, (__bf16*)packed, bias_packed);
@@ -2219,7 +2239,7 @@ static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_
                              uint32_t* y_max, int64_t B, int in, int out, int relu_in, int relu_out,
                              int dtype, int k_reverse, void* stream) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
-    if (!split_terms(dtype)) return NF_ERR_DTYPE;
+    if (!linear_terms(dtype)) return NF_ERR_DTYPE;
     hipStream_t s = (hipStream_t)stream;
     if (y_max) {
         hipError_t me = hipMemsetAsync(y_max, 0, sizeof(uint32_t), s);
@@ -2241,9 +2261,10 @@ static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
     g.vec_out = out % 4 == 0 && y_row_stride % 4 == 0 && ((uintptr_t)y & 15) == 0 &&
                 (!residual || (res_row_stride % 4 == 0 && ((uintptr_t)residual & 15) == 0));
-    const size_t stages = (size_t)2 * 2 * split_terms(dtype) * XA, otile = sizeof(float) * (XT / 64) * 32 * XOT;
+    const size_t stages = (size_t)2 * 2 * linear_terms(dtype) * XA, otile = sizeof(float) * (XT / 64) * 32 * XOT;
     const size_t lds = g.vec_out && otile > stages ? otile : stages;
     return dtype == NF_DTYPE_BF16X3 ? launch_linear_split<SplitBf16x3>(g, (int)grid, lds, relu_in, s)
+           : dtype == NF_DTYPE_BF16 ? launch_linear_split<SplitBf16x1>(g, (int)grid, lds, relu_in, s)
                                     : launch_linear_split<SplitF16x2>(g, (int)grid, lds, relu_in, s);
 }
 

@@ -21,7 +21,9 @@ from . import _lib
 
 _MATMUL_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_BF16X3,
                  'f16x2': _lib.NF_DTYPE_F16X2}
-_SPLIT_MODES = ('bf16x3', 'f16x2')
+# modes whose hidden-layer GEMMs run on the split-operand kernel (nf_masked_linear_split_fwd): the two split modes, and
+# 'bf16' as that kernel's one-term flavour (plain bf16 operands, one MFMA per product)
+_SPLIT_MODES = ('bf16x3', 'f16x2', 'bf16')
 # hidden-layer GEMMs the split kernel does not take (BatchNorm prologue, tile windows, ragged K) stay on fp32 MFMA
 _GEMM_DTYPE = {'f32': _lib.NF_DTYPE_F32, 'bf16': _lib.NF_DTYPE_BF16, 'bf16x3': _lib.NF_DTYPE_F32,
                'f16x2': _lib.NF_DTYPE_F32}
@@ -113,6 +115,17 @@ class _PackedMixin:
                                          _MATMUL_DTYPE[get_matmul_dtype()], reuse=cached[1] if same_mask else None)
             object.__setattr__(self, '_split_t_cache', (key, pls))
             cached = self._split_t_cache
+        return cached[1]
+
+    def _wgrad_ktab(self):
+        """K-tile table of the 128-row output tiles (nf_made_pack's) for the weight-gradient kernels: a function of the
+        mask only, so it is built once and kept across optimizer steps."""
+        mask = getattr(self, 'mask', None)
+        key = (None if mask is None else (mask._version, mask.data_ptr()), self.weight.device, tuple(self.weight.shape))
+        cached = getattr(self, '_ktab_cache', None)
+        if cached is None or cached[0] != key:
+            cached = (key, _lib.PackedLinear(self.weight, mask, None, _lib.NF_DTYPE_F32).ktab)
+            object.__setattr__(self, '_ktab_cache', cached)
         return cached[1]
 
     def _packed_fused_final(self, features, num_bins, tails, logit_div=1.0):
