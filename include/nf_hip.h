@@ -230,6 +230,13 @@ int nf_linear_split_pack(const float* W, const float* mask, const float* bias, i
  * rewritten, the K-range table in ktab (a scan of the whole mask) is kept.  Training repacks every step. */
 int nf_linear_split_repack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
                          void* packed, int32_t* ktab, float* bias_packed, void* stream);
+/* The pack of the TRANSPOSED layer (weight operand of grad_x = grad_y @ (W * mask), autograd of made.py:150-152) read
+ * from the layer's own [out, in] arrays: packed_t per nf_linear_split_packed_bytes(in, out, dtype), ktab_t
+ * 2 * nf_linear_split_tiles(in) + 2 int32, bias_zero 256 * nf_linear_split_tiles(in) floats (zero filled here).
+ * fresh = 0 keeps the K-range table (mask unchanged since the last call on these buffers).  Also accepts
+ * NF_DTYPE_BF16 like the calls above: one bf16 term per operand, the 2e-2 mode. */
+int nf_linear_split_pack_t(const float* W, const float* mask, int out, int in, int dtype, void* packed_t,
+                           int32_t* ktab_t, float* bias_zero, int fresh, void* stream);
 /* slot <- bit pattern of the largest finite |x[b, c]| (any width / alignment; 16-byte loads when cols % 4 == 0 and
  * the rows are 16-byte aligned). */
 int nf_maxabs(const float* x, int64_t x_row_stride, int64_t B, int cols, uint32_t* slot, void* stream);

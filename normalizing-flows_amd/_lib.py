@@ -104,6 +104,8 @@ _SIGNATURES = {
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     'nf_linear_split_repack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
                                           _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'nf_linear_split_pack_t': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+                                          _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p]),
     'nf_masked_linear_split_bwd_weight': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                                       _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                       _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
@@ -277,14 +279,20 @@ class PackedLinearSplit:
     """Device buffers of nf_linear_split_pack: one [out,in] layer as fp16 / bf16 term planes in 256-row tiles."""
     __slots__ = ('out', 'inp', 'dtype', 'packed', 'ktab', 'bias', 'tiles')
 
-    def __init__(self, weight, mask, bias, dtype, reuse=None):
+    def __init__(self, weight, mask, bias, dtype, reuse=None, transposed=False):
         """reuse: the previous pack of the same layer with the same mask - its buffers and K-range table are kept
-        (nf_linear_split_repack), only the weights, bias and operand scale are rewritten."""
+        (nf_linear_split_repack), only the weights, bias and operand scale are rewritten.
+        transposed: pack the layer's transpose (the input-gradient GEMM's operand, out / inp swapped, no bias) straight
+        from weight / mask as stored (nf_linear_split_pack_t)."""
         lib = load()
         w = _dev(weight.detach().contiguous(), 'weight')
         m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
         b = None if bias is None else _dev(bias.detach().contiguous(), 'bias')
         self.out, self.inp, self.dtype = int(w.shape[0]), int(w.shape[1]), dtype
+        if transposed:
+            if bias is not None:
+                raise ValueError('the transposed pack takes no bias')
+            self.out, self.inp = self.inp, self.out
         self.tiles = lib.nf_linear_split_tiles(self.out)
         fresh = reuse is None or (reuse.out, reuse.inp, reuse.dtype) != (self.out, self.inp, dtype) \
             or reuse.packed.device != w.device
@@ -297,8 +305,13 @@ class PackedLinearSplit:
             self.packed, self.ktab, self.bias = reuse.packed, reuse.ktab, reuse.bias
         fn = lib.nf_linear_split_pack if fresh else lib.nf_linear_split_repack
         with torch.cuda.device(w.device):
-            _check(fn(w.data_ptr(), _ptr(m), _ptr(b), self.out, self.inp, dtype, self.packed.data_ptr(),
-                      self.ktab.data_ptr(), self.bias.data_ptr(), _stream()), 'nf_linear_split_pack')
+            if transposed:
+                _check(lib.nf_linear_split_pack_t(w.data_ptr(), _ptr(m), self.inp, self.out, dtype,
+                                                  self.packed.data_ptr(), self.ktab.data_ptr(), self.bias.data_ptr(),
+                                                  int(fresh), _stream()), 'nf_linear_split_pack_t')
+            else:
+                _check(fn(w.data_ptr(), _ptr(m), _ptr(b), self.out, self.inp, dtype, self.packed.data_ptr(),
+                          self.ktab.data_ptr(), self.bias.data_ptr(), _stream()), 'nf_linear_split_pack')
 
 
 def split_gemm_supported(x, in_features):

@@ -417,7 +417,7 @@ __global__ void pack_fused_kernel(const float* __restrict__ W, const float* __re
 }
 
 __global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict__ mask, int out, int in,
-                                                         int src_rows, int32_t* __restrict__ ktab) {
+                                                         int src_rows, int32_t* __restrict__ ktab, int transposed) {
     __shared__ int lo, hi;
     const int tn = blockIdx.x;
     if (threadIdx.x == 0) { lo = 0x7fffffff; hi = -1; }
@@ -428,7 +428,8 @@ __global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict
     if (mask) {
         for (int64_t i = threadIdx.x; i < (int64_t)rows * in; i += blockDim.x) {
             const int r = (int)(i / in), k = (int)(i - (int64_t)r * in);
-            if (mask[(int64_t)(row0 + r) * in + k] != 0.0f) { mylo = min(mylo, k); myhi = max(myhi, k); }
+            const int64_t at = transposed ? (int64_t)k * out + row0 + r : (int64_t)(row0 + r) * in + k;
+            if (mask[at] != 0.0f) { mylo = min(mylo, k); myhi = max(myhi, k); }
         }
     } else if (rows > 0) {
         mylo = 0;
@@ -1424,7 +1425,8 @@ __global__ void pack_fused_split_kernel(const float* __restrict__ W, const float
                                         const float* __restrict__ bias, int out, int in, int src_rows, int kpad,
                                         int64_t total, int P, int n_logits, float logit_fold,
                                         const unsigned* __restrict__ wmax, typename SP::elem* __restrict__ packed,
-                                        float* __restrict__ bias_packed) {
+                                        float* __restrict__ bias_packed, int transposed) {
+    // transposed: W / mask are stored [in][out] (the layer's own arrays, packed here as the input-gradient GEMM's operand)
     constexpr int NT = SP::NT;
     const int nsteps = kpad / XS;
     float sw = 1.f, swi = 1.f;
@@ -1444,8 +1446,9 @@ __global__ void pack_fused_split_kernel(const float* __restrict__ W, const float
         const float fold = (j % P) < n_logits ? logit_fold : 1.0f;
         float v = 0.0f;
         if (live && k < in) {
-            v = W[n * in + k];
-            if (mask) v *= mask[n * in + k];
+            const int64_t at = transposed ? (int64_t)k * out + n : n * in + k;
+            v = W[at];
+            if (mask) v *= mask[at];
             v *= fold;
         }
         typename SP::elem t[NT];
@@ -2014,7 +2017,7 @@ extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const 
     if (dtype == NF_DTYPE_BF16X3) {
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x3>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in,
                            fpt * P, kpad, 3 * total, P, 2 * K, logit_fold, (const unsigned*)nullptr, (__bf16*)packed,
-                           bias_packed);
+                           bias_packed, 0);
     } else if (dtype == NF_DTYPE_F16X2) {
         if (!ktab) return NF_ERR_NULL;                 // the scale pair lives after the table
         unsigned* slot = (unsigned*)(ktab + 2 * nt);
@@ -2025,14 +2028,14 @@ extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const 
         hipLaunchKernelGGL(maxabs_kernel, dim3(mgrid), dim3(256), 0, s, W, mask, nw, P, in, 2 * K, logit_fold, slot);
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitF16x2>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in,
                            fpt * P, kpad, 2 * total, P, 2 * K, logit_fold, (const unsigned*)slot, (_Float16*)packed,
-                           bias_packed);
+                           bias_packed, 0);
     } else if (dtype == NF_DTYPE_F32)
         hipLaunchKernelGGL(pack_fused_kernel<float>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
                            total, P, 2 * K, logit_fold, (float*)packed, bias_packed);
     else
         hipLaunchKernelGGL(pack_fused_kernel<__bf16>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
                            total, P, 2 * K, logit_fold, (__bf16*)packed, bias_packed);
-    if (ktab) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, fpt * P, ktab);
+    if (ktab) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, fpt * P, ktab, 0);
     return nf_launch_status();
 }
 
@@ -2175,7 +2178,8 @@ extern "C" size_t nf_linear_split_packed_bytes(int out, int in, int dtype) {
 }
 
 static int linear_split_pack_impl(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
-                                  void* packed, int32_t* ktab, float* bias_packed, bool table, void* stream) {
+                                  void* packed, int32_t* ktab, float* bias_packed, bool table, void* stream,
+                                  int transposed = 0) {
     if (!W || !packed || !ktab || !bias_packed) return NF_ERR_NULL;
     if (out <= 0 || in <= 0) return NF_ERR_SHAPE;
     if (!linear_terms(dtype)) return NF_ERR_DTYPE;
@@ -2189,17 +2193,19 @@ static int linear_split_pack_impl(const float* W, const float* mask, const float
     if (dtype == NF_DTYPE_F16X2) {
         const int64_t nw = (int64_t)out * in;
         const int mgrid = out < 1024 ? out : 1024;
-        hipLaunchKernelGGL(maxabs_kernel, dim3(mgrid), dim3(256), 0, s, W, mask, nw, 1, in, 0, 1.0f, slot);
+        // (the largest |W * mask| does not depend on the orientation: scanned along the rows as stored)
+        hipLaunchKernelGGL(maxabs_kernel, dim3(transposed ? (in < 1024 ? in : 1024) : mgrid), dim3(256), 0, s, W, mask, nw,
+                           1, transposed ? out : in, 0, 1.0f, slot);
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitF16x2>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
-                           kpad, total, 1, 0, 1.0f, (const unsigned*)slot, (_Float16*)packed, bias_packed);
+                           kpad, total, 1, 0, 1.0f, (const unsigned*)slot, (_Float16*)packed, bias_packed, transposed);
     } else if (dtype == NF_DTYPE_BF16) {
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x1>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
-                           kpad, total, 1, 0, 1.0f, (const unsigned*)nullptr, (__bf16*)packed, bias_packed);
+                           kpad, total, 1, 0, 1.0f, (const unsigned*)nullptr, (__bf16*)packed, bias_packed, transposed);
     } else {
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x3>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
-                           kpad, total, 1, 0, 1.0f, (const unsigned*)nullptr, (__bf16*)packed, bias_packed);
+                           kpad, total, 1, 0, 1.0f, (const unsigned*)nullptr, (__bf16*)packed, bias_packed, transposed);
     }
-    if (table) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, FN, ktab);
+    if (table) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, FN, ktab, transposed);
     return nf_launch_status();
 }
 
@@ -2211,6 +2217,16 @@ extern "C" int nf_linear_split_pack(const float* W, const float* mask, const flo
 extern "C" int nf_linear_split_repack(const float* W, const float* mask, const float* bias, int out, int in, int dtype,
                                       void* packed, int32_t* ktab, float* bias_packed, void* stream) {
     return linear_split_pack_impl(W, mask, bias, out, in, dtype, packed, ktab, bias_packed, false, stream);
+}
+
+// The pack of the TRANSPOSED layer - the weight operand of grad_x = grad_y @ (W * mask), a logical [in, out] matrix -
+// read from the layer's own [out, in] arrays (no transposed copies of W and the mask per optimizer step).  Buffer
+// sizes: nf_linear_split_packed_bytes(in, out, dtype), 2 * nf_linear_split_tiles(in) + 2 table entries, 256 *
+// nf_linear_split_tiles(in) bias floats (zeroed: the input gradient has no bias).  fresh = 0: the mask is unchanged
+// since the last call on these buffers, keep the K-range table.
+extern "C" int nf_linear_split_pack_t(const float* W, const float* mask, int out, int in, int dtype, void* packed_t,
+                                      int32_t* ktab_t, float* bias_zero, int fresh, void* stream) {
+    return linear_split_pack_impl(W, mask, nullptr, in, out, dtype, packed_t, ktab_t, bias_zero, fresh != 0, stream, 1);
 }
 
 extern "C" int nf_maxabs(const float* x, int64_t x_row_stride, int64_t B, int cols, uint32_t* slot, void* stream) {

@@ -110,9 +110,8 @@ class _PackedMixin:
         cached = getattr(self, '_split_t_cache', None)
         if cached is None or cached[0] != key:
             same_mask = cached is not None and cached[0][-1] == key[-1]
-            pls = _lib.PackedLinearSplit(self.weight.detach().t().contiguous(),
-                                         None if mask is None else mask.t().contiguous(), None,
-                                         _MATMUL_DTYPE[get_matmul_dtype()], reuse=cached[1] if same_mask else None)
+            pls = _lib.PackedLinearSplit(self.weight, mask, None, _MATMUL_DTYPE[get_matmul_dtype()],
+                                         reuse=cached[1] if same_mask else None, transposed=True)
             object.__setattr__(self, '_split_t_cache', (key, pls))
             cached = self._split_t_cache
         return cached[1]
