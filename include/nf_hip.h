@@ -389,7 +389,9 @@ int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, cons
 
 /* The same weight gradient with ONE scaled fp16 term per operand (11 significant bits relative to each tensor's largest
  * element, fp32 accumulation, a third of the MFMAs): what the bf16 training mode uses (BASELINE config 5 "bf16 MADE
- * MFMA backward"; 2e-2 tolerance class).  Same arguments. */
+ * MFMA backward"; 2e-2 tolerance class).  Same arguments, plus an optional caller-owned `workspace` (NULL = none) of at
+ * least B * in * 2 bytes, 16-byte aligned: wide layers (more than 128 output tiles of 128 x 256) then carry act(x) as an
+ * fp16 plane written there first and fetched by LDS-DMA (half the bytes of the operand every workgroup re-reads). */
 int nf_masked_linear_half_bwd_weight(const float* x, int64_t x_row_stride, const uint32_t* x_max,
                                      const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
                                      const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,

@@ -985,6 +985,8 @@ struct WgradSplitArgs {
     float* gb;               // nullable: column sums of grad_y, accumulated by the tk == 0 blocks
     int64_t M;
     int out, in, relu_in, splits;
+    const _Float16* xh;      // wgrad_tr_kernel<true>: act(x) * 2^e as an fp16 plane [M][ldxh]
+    int64_t ldxh;
     int nt, kt, group;       // tiles along out / in; consecutive work items kept on one XCD
 };
 
@@ -1210,23 +1212,58 @@ __device__ __forceinline__ int wt_off(int row, int ch) {     // byte offset of 1
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
+// x as a pre-converted plane (XP): act(x) * 2^e in fp16, [M][in] row-major (half_plane_kernel), fetched global -> LDS by
+// LDS-DMA with the swizzle applied on the global side (lane l of a 1 KB piece = LDS chunk position l & 15 of row l >> 4
+// fetches logical chunk position ^ swizzle(row)): half the bytes of the fp32 rows through L2 -> CU, which is what
+// bounds this kernel (every workgroup of a batch split re-reads the same x chunk), no staging registers and no
+// conversion work for x in the loop.  Three x buffers: the DMA of chunk s + 2 is issued in step s.
+__global__ __launch_bounds__(256) void half_plane_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int K,
+                                                         const unsigned* __restrict__ x_max, int relu,
+                                                         _Float16* __restrict__ plane) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    float sx, ix;
+    pow2_pair(*x_max, sx, ix);
+    const int cpr = K / 4;
+    const int64_t total = M * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) * 4;
+        float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const h4 hv = {(_Float16)(v.x * sx), (_Float16)(v.y * sx), (_Float16)(v.z * sx), (_Float16)(v.w * sx)};
+        *reinterpret_cast<h4*>(plane + r * K + c) = hv;
+    }
+}
+
+// one LDS-DMA wave-instruction: lane l's 16 bytes at gsrc land at lds_dst + 16 l (lds_dst wave-uniform); M0 is
+// compiler-reserved: saved and restored around the instruction
+__device__ __forceinline__ void wt_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <bool XP>
 __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef short s4 __attribute__((ext_vector_type(4)));
     typedef short s8 __attribute__((ext_vector_type(8)));
     typedef __attribute__((address_space(3))) s4* lds_s4;
-    constexpr int NIMG = 1 + WT_K / 128;             // images per buffer: grad_y + x
-    constexpr int XL = WT_K / 64;                    // 16-byte x loads per thread and chunk
+    constexpr int NXI = WT_K / 128;                  // x images of a chunk
+    constexpr int XL = WT_K / 64;                    // 16-byte x loads per thread and chunk (fp32 rows)
     constexpr int XG = WT_K / 4;                     // four-column groups of an x row
     constexpr int NJ = WT_K / 128;                   // 32-column blocks of a wave along the input width
-    extern __shared__ __attribute__((aligned(16))) char wt_lds[];       // [2 buffers][NIMG images][8 KB]
+    // LDS: XP ? [2 grad_y images][3 x buffers of NXI images] : [2 buffers of (grad_y image + NXI x images)]
+    extern __shared__ __attribute__((aligned(16))) char wt_lds[];
+    auto ybase = [&](int buf) { return wt_lds + (XP ? buf * WT_IMG : buf * (1 + NXI) * WT_IMG); };
+    auto xbase = [&](int buf) { return wt_lds + (XP ? (2 + buf * NXI) * WT_IMG : (buf * (1 + NXI) + 1) * WT_IMG); };
     const int slot = blockIdx.x >> 3;
     const int64_t w = ((int64_t)(slot / g.group) * 8 + (blockIdx.x & 7)) * g.group + slot % g.group;
     if (w >= (int64_t)g.nt * g.kt * g.splits) return;
     const int tk = (int)(w % g.kt), tn = g.nt - 1 - (int)((w / g.kt) % g.nt), split = (int)(w / ((int64_t)g.kt * g.nt));
     const int n0 = tn * WT_N, k0 = tk * WT_K;
     const bool do_bias = g.gb != nullptr && tk == 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;         // wave tile: 64 (out) x WT_K / 4 (in)
     // live K range of this tile's 128 output rows (forward table, 32-wide units): a wave whose input columns lie
     // outside it has only masked weights to produce
@@ -1252,14 +1289,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // fetch map: grad_y chunk = 32 rows x 32 four-column groups, thread = group (tid & 31) x rows (tid >> 5) + 16 e;
-    // x chunk = 32 rows x XG groups, thread = group (tid % XG) x rows (tid / XG) + (512 / XG) e.  Columns past the matrix
-    // edge are clamped (they only reach accumulator entries that are never stored), rows past the batch end are clamped
-    // and scaled by 0.  Every load is unconditional: a load under a branch makes hipcc wait vmcnt(0) at each use.
+    // x chunk (fp32 rows) = 32 rows x XG groups, thread = group (tid % XG) x rows (tid / XG) + (512 / XG) e.  Columns past
+    // the matrix edge are clamped (they only reach accumulator entries that are never stored), rows past the batch end
+    // are clamped and grad_y's are scaled by 0.  Every load is unconditional: a load under a branch makes hipcc wait
+    // vmcnt(0) at each use.
     const int ycg = tid & 31, yr0 = tid >> 5, xcg = tid % XG, xr0 = tid / XG;
     const float* ycol = g.gy + min(n0 + 4 * ycg, g.out - 4);
     const float* xcol = g.x + min(k0 + 4 * xcg, g.in - 4);
     // grad_y comes from HBM: three chunks of it in flight; x is the same for every workgroup of a batch split (L2): two
-    float4 cy[3][2], cx[2][XL];
+    float4 cy[3][2], cx[XP ? 1 : 2][XL];
     auto load_y = [&](int c, int64_t b0) {
 #ifndef NF_WT_KO_LOADS
 #pragma unroll
@@ -1269,15 +1307,37 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
     };
     auto load_x = [&](int c, int64_t b0) {
 #ifndef NF_WT_KO_LOADS
+        if (XP) return;
 #pragma unroll
         for (int e = 0; e < XL; ++e)
             cx[c][e] = *reinterpret_cast<const float4*>(xcol + min(b0 + xr0 + (512 / XG) * e, b_end - 1) * g.ldx);
 #endif
     };
+    // XP: the chunk's NXI * 8 one-KB pieces (4 rows of an image each) are spread over the 8 waves, NXI per wave
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wt_lds;
+    const _Float16* xsrc[NXI];
+    int xrow[NXI];
+    unsigned xdst[NXI];
+#pragma unroll
+    for (int t = 0; t < NXI; ++t) {
+        const int piece = NXI * wave + t, img = piece >> 3, q = piece & 7;
+        const int row = 4 * q + (lane >> 4);
+        const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        xrow[t] = row;
+        xsrc[t] = g.xh + min(k0 + img * 128 + 8 * ch, g.in - 8);
+        xdst[t] = (unsigned)(2 * WT_IMG + img * WT_IMG + q * 1024);
+    }
+    auto dma_x = [&](int buf, int64_t b0) {
+#ifndef NF_WT_KO_LOADS
+#pragma unroll
+        for (int t = 0; t < NXI; ++t)
+            wt_glds16(xsrc[t] + min(b0 + xrow[t], b_end - 1) * g.ldxh, lds0 + xdst[t] + buf * NXI * WT_IMG);
+#endif
+    };
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};            // in grad_y's scaled units: this thread's four columns
     auto convert = [&](int yc, int xc, int64_t b0, int buf) {
 #ifndef NF_WT_KO_CONV
-        char* base = wt_lds + buf * NIMG * WT_IMG;
+        char* yb = ybase(buf);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int r = yr0 + 16 * e;
@@ -1285,22 +1345,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
             const float v0 = cy[yc][e].x * sc, v1 = cy[yc][e].y * sc, v2 = cy[yc][e].z * sc, v3 = cy[yc][e].w * sc;
             bsum[0] += v0; bsum[1] += v1; bsum[2] += v2; bsum[3] += v3;
             h4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
-            *reinterpret_cast<h4*>(base + wt_off(r, ycg >> 1) + 8 * (ycg & 1)) = hv;
+            *reinterpret_cast<h4*>(yb + wt_off(r, ycg >> 1) + 8 * (ycg & 1)) = hv;
         }
+        if (XP) return;
+        char* xb = xbase(buf);
 #pragma unroll
         for (int e = 0; e < XL; ++e) {
             const int r = xr0 + (512 / XG) * e;
             float v0 = cx[xc][e].x, v1 = cx[xc][e].y, v2 = cx[xc][e].z, v3 = cx[xc][e].w;
             if (g.relu_in) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             h4 hv = {(_Float16)(v0 * sx), (_Float16)(v1 * sx), (_Float16)(v2 * sx), (_Float16)(v3 * sx)};
-            *reinterpret_cast<h4*>(base + (1 + (xcg >> 5)) * WT_IMG + wt_off(r, (xcg & 31) >> 1) + 8 * (xcg & 1)) = hv;
+            *reinterpret_cast<h4*>(xb + (xcg >> 5) * WT_IMG + wt_off(r, (xcg & 31) >> 1) + 8 * (xcg & 1)) = hv;
         }
 #endif
     };
     // transposed operand reads: group gq = lane >> 4 of 16 lanes, lane 4q + p of it addresses row q, columns 4p..4p+3 of
     // its block and receives column (lane & 15); block = rows 16 ks + 8 (gq >> 1) + 4 t .. + 3, columns base + 16 (gq & 1)
     const int gq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-    int aoff[2][2], boff[NJ][2];                     // [i or j][t]: byte offsets inside a buffer, ks = 0
+    int aoff[2][2], boff[NJ][2];                     // [i or j][t]: byte offsets inside the grad_y image / x images, ks = 0
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int row = 8 * (gq >> 1) + 4 * t + tq;
@@ -1310,29 +1372,30 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int col = cw + 32 * j + 16 * (gq & 1);             // of the x chunk's WT_K columns
-            boff[j][t] = (1 + col / 128) * WT_IMG + wt_off(row, (col % 128) / 8 + (tp >> 1)) + 8 * (tp & 1);
+            boff[j][t] = (col / 128) * WT_IMG + wt_off(row, (col % 128) / 8 + (tp >> 1)) + 8 * (tp & 1);
         }
     }
     auto rd = [&](const char* base, int off) {
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(base + off));
     };
-    auto mma = [&](int buf) {
+    auto mma = [&](int ybuf, int xbuf) {
 #ifndef NF_WT_KO_MMA
         if (!live) return;                           // wave-uniform
-        const char* base = wt_lds + buf * NIMG * WT_IMG;
+        const char* yb = ybase(ybuf);
+        const char* xb = xbase(xbuf);
 #pragma unroll
         for (int ks = 0; ks < WSB / 16; ++ks) {
             f16x8 a[2], b[NJ];
             // (rows + 16 ks: 4096 bytes further, the swizzle does not involve that bit)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const s4 lo = rd(base, aoff[i][0] + 4096 * ks), hi = rd(base, aoff[i][1] + 4096 * ks);
+                const s4 lo = rd(yb, aoff[i][0] + 4096 * ks), hi = rd(yb, aoff[i][1] + 4096 * ks);
                 const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 a[i] = __builtin_bit_cast(f16x8, v);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const s4 lo = rd(base, boff[j][0] + 4096 * ks), hi = rd(base, boff[j][1] + 4096 * ks);
+                const s4 lo = rd(xb, boff[j][0] + 4096 * ks), hi = rd(xb, boff[j][1] + 4096 * ks);
                 const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 b[j] = __builtin_bit_cast(f16x8, v);
             }
@@ -1345,41 +1408,51 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
 #endif
     };
     // the step barrier orders LDS traffic only: __syncthreads() would also drain vmcnt, i.e. wait out the chunks
-    // requested steps ahead on purpose
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // requested steps ahead on purpose.  XP: the DMA pieces of chunk s + 1, which the next step reads, must have landed
+    // - after them this wave issued 2 grad_y loads in their own step (s - 1) and NXI + 2 operations in this one (loads return
+    // in order; hipcc's own counts for the grad_y registers only become stricter by the DMA operations it cannot see)
+    auto lds_barrier = [] {
+        if (XP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NXI + 2) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
     // Waves w and w + 4 share a SIMD and take the two halves of a step - the MFMAs of chunk s (reads buffer s & 1) and
     // the conversion of chunk s + 1 (writes the other buffer) - in opposite order: one's vector-ALU / LDS work runs
     // under the other's MFMAs instead of all eight waves queueing on the same pipe in lockstep.
-    const bool mma_first = __builtin_amdgcn_readfirstlane(wave >> 2) != 0;
+    const bool mma_first = (wave >> 2) != 0;
     // step s (chunk s = rows b_begin + 32 s ..): convert chunk s + 1 (grad_y set (s + 1) % 3, x set (s + 1) & 1) into
-    // LDS buffer (s + 1) & 1 - its last readers passed the previous barrier -, request x chunk s + 3 and then grad_y
-    // chunk s + 4 into the sets just freed (x first: loads return in order, and the next step's wait for its x must
-    // not include a fresh HBM fetch), and run the MFMAs of chunk s.  Unrolled by 6: every set / buffer index constant.
+    // LDS buffer (s + 1) & 1 - its last readers passed the previous barrier -, request x chunk s + 3 (XP: DMA chunk
+    // s + 2 into x buffer (s + 2) % 3, last read in step s - 1) and then grad_y chunk s + 4 into the sets just freed
+    // (x first: loads return in order, and the next step's wait for its x must not include a fresh HBM fetch), and run
+    // the MFMAs of chunk s.  Unrolled by 6: every set / buffer index constant.
     // No exit inside the six steps (an early exit gives the loop header a second predecessor whose loads were issued
     // one step ago, and hipcc then waits for ALL loads in step 0): steps past the batch end multiply zeros.
     load_y(0, b_begin);
     load_x(0, b_begin);
+    if (XP) { dma_x(0, b_begin); dma_x(1, b_begin + WSB); }
     load_y(1, b_begin + WSB);
     load_x(1, b_begin + WSB);
     load_y(2, b_begin + 2 * WSB);
     convert(0, 0, b_begin, 0);
     load_x(0, b_begin + 2 * WSB);
     load_y(0, b_begin + 3 * WSB);
+    if (XP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #define WT_STEP(S_)                                                                       \
     {                                                                                     \
         const int64_t bs_ = b0 + (S_) * WSB;                                              \
-        if (mma_first) { mma((S_) & 1); __builtin_amdgcn_sched_barrier(0); }              \
+        if (mma_first) { mma((S_) & 1, XP ? (S_) % 3 : (S_) & 1); __builtin_amdgcn_sched_barrier(0); } \
         convert(((S_) + 1) % 3, ((S_) + 1) & 1, bs_ + WSB, ((S_) + 1) & 1);               \
-        load_x(((S_) + 1) & 1, bs_ + 3 * WSB);                                            \
+        if (XP) dma_x(((S_) + 2) % 3, bs_ + 2 * WSB);                                     \
+        else load_x(((S_) + 1) & 1, bs_ + 3 * WSB);                                       \
         load_y(((S_) + 1) % 3, bs_ + 4 * WSB);                                            \
-        if (!mma_first) { __builtin_amdgcn_sched_barrier(0); mma((S_) & 1); }             \
+        if (!mma_first) { __builtin_amdgcn_sched_barrier(0); mma((S_) & 1, XP ? (S_) % 3 : (S_) & 1); } \
         lds_barrier();                                                                    \
     }
     for (int64_t b0 = b_begin; b0 < b_end; b0 += 6 * WSB) {
         WT_STEP(0) WT_STEP(1) WT_STEP(2) WT_STEP(3) WT_STEP(4) WT_STEP(5)
     }
 #undef WT_STEP
+    if (XP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // DMA pieces still in flight target LDS
     if (do_bias) {           // the 16 threads that share a column group add up through LDS (fixed order), one atomic each
         __syncthreads();
         float* red = reinterpret_cast<float*>(wt_lds);           // [16][128]
@@ -2287,7 +2360,7 @@ static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_
 static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t* x_max, const float* grad_y,
                             int64_t grad_y_row_stride, const uint32_t* grad_y_max, const float* mask,
                             const int32_t* ktab, float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
-                            int terms, void* stream) {
+                            int terms, void* stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (B == 0) return NF_OK;
     if (!x || !grad_y || !grad_w || !x_max || !grad_y_max) return NF_ERR_NULL;
@@ -2296,7 +2369,7 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
     WgradSplitArgs g;
     g.x = x; g.ldx = x_row_stride; g.gy = grad_y; g.ldgy = grad_y_row_stride; g.x_max = (const unsigned*)x_max;
     g.gy_max = (const unsigned*)grad_y_max; g.mask = mask; g.ktab = ktab; g.gw = grad_w; g.gb = grad_b; g.M = B; g.out = out; g.in = in;
-    g.relu_in = relu_in;
+    g.relu_in = relu_in; g.xh = nullptr; g.ldxh = 0;
     const int tw = out >= 2048 ? 2 : 1;                                  // wide layers: 256-row tiles, one workgroup per CU
     const int nt = (out + 128 * tw - 1) / (128 * tw), kt = (in + 127) / 128;
     int64_t splits = 3072 / tw / ((int64_t)nt * kt) + 1;
@@ -2338,9 +2411,22 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
         const int64_t gd = (wk + g.group - 1) / g.group * g.group;
         const int64_t bk = (gd / g.group + 7) / 8 * 8 * g.group;
         if (bk > 0x7fffffff) return NF_ERR_SHAPE;
-        static unsigned long long tr_cap = 0;
-        if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel, &tr_cap)) return e;
-        hipLaunchKernelGGL(wgrad_tr_kernel, dim3((unsigned)bk), dim3(512), 2 * (1 + WT_K / 128) * WT_IMG, s, g);
+        static unsigned long long tr_cap[2] = {0, 0};
+        // a wide layer with a caller's workspace: x goes through its fp16 plane (every workgroup of a batch split
+        // re-reads the x chunk: half the bytes, no conversion in the loop); a layer of a few tiles reads x too
+        // rarely for the extra pass to pay
+        if (workspace && tiles > 128 && in % 8 == 0 && ((uintptr_t)workspace & 15) == 0 &&
+            workspace_bytes >= (size_t)B * in * sizeof(_Float16)) {
+            g.xh = (const _Float16*)workspace; g.ldxh = in;
+            const int64_t quads = B * (in / 4);
+            hipLaunchKernelGGL(half_plane_kernel, dim3((unsigned)(quads / 256 < 4096 ? quads / 256 + 1 : 4096)), dim3(256), 0, s,
+                               x, x_row_stride, B, in, g.x_max, relu_in, (_Float16*)workspace);
+            if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<true>, &tr_cap[1])) return e;
+            hipLaunchKernelGGL(wgrad_tr_kernel<true>, dim3((unsigned)bk), dim3(512), (2 + 3 * (WT_K / 128)) * WT_IMG, s, g);
+            return nf_launch_status();
+        }
+        if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<false>, &tr_cap[0])) return e;
+        hipLaunchKernelGGL(wgrad_tr_kernel<false>, dim3((unsigned)bk), dim3(512), 2 * (1 + WT_K / 128) * WT_IMG, s, g);
         return nf_launch_status();
     }
     if (terms == 2 && tw == 2) hipLaunchKernelGGL((wgrad_split_kernel<2, SplitF16x2>), gr, bl, lds, s, g);
@@ -2387,9 +2473,9 @@ extern "C" int nf_masked_linear_half_bwd_weight(const float* x, int64_t x_row_st
                                                 const float* grad_y, int64_t grad_y_row_stride,
                                                 const uint32_t* grad_y_max, const float* mask, const int32_t* ktab,
                                                 float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
-                                                void* stream) {
+                                                void* workspace, size_t workspace_bytes, void* stream) {
     return wgrad_split_impl(x, x_row_stride, x_max, grad_y, grad_y_row_stride, grad_y_max, mask, ktab, grad_w, grad_b, B,
-                            in, out, relu_in, 1, stream);
+                            in, out, relu_in, 1, stream, workspace, workspace_bytes);
 }
 
 // ---- the one entry point that allocates nothing and takes no workspace ---------------------------------

@@ -2322,11 +2322,13 @@ def test_cubic_coupling_with_unconditional_transform_golden(nf):
     assert torch.quantile((b - z).abs().reshape(-1), 0.99).item() < 1e-3
 
 
-@pytest.mark.parametrize('shape', [(1000, 132, 2052, True), (4096, 512, 4600, False), (70, 8, 2048, True)])
+@pytest.mark.parametrize('shape', [(1000, 132, 2052, True), (4096, 512, 4600, False), (70, 8, 2048, True),
+                                   (1500, 512, 9000, True), (333, 264, 16500, False)])
 def test_half_precision_weight_gradient_transposed_read_kernel(nf, shape):
     """nf_masked_linear_half_bwd_weight on wide layers (>= 2048 outputs: wgrad_tr_kernel, row-wise fetches + transposing
     LDS reads) against the fp64 product: ragged batch / widths, ReLU on x, mask, bias gradient; and against the
-    4-byte-fetch kernel it replaces (same operands, same fp16 rounding: equal up to fp32 summation order)."""
+    4-byte-fetch kernel it replaces (same operands, same fp16 rounding: equal up to fp32 summation order).  The last two
+    shapes have more than 128 output tiles: x then goes through its fp16 plane in the workspace and LDS-DMA."""
     B, inp, out, relu = shape
     g = torch.Generator(device='cuda').manual_seed(B + out)
     x = torch.randn(B, inp, device='cuda', generator=g)
