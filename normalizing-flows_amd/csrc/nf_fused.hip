@@ -416,32 +416,66 @@ __global__ void pack_fused_kernel(const float* __restrict__ W, const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void ktab_fused_kernel(const float* __restrict__ mask, int out, int in,
-                                                         int src_rows, int32_t* __restrict__ ktab, int transposed) {
-    __shared__ int lo, hi;
-    const int tn = blockIdx.x;
-    if (threadIdx.x == 0) { lo = 0x7fffffff; hi = -1; }
-    __syncthreads();
-    int mylo = 0x7fffffff, myhi = -1;
+// K-range table of the packed tiles: [tile][first, one-past-last 16-wide K step with an unmasked weight].  A function of
+// the mask only (built at the first pack of a layer, kept across repacks).  Three small launches: raw column bounds
+// reset, a scan with KTAB_SLICES workgroups per tile whose consecutive threads read consecutive addresses in either
+// orientation (one workgroup per tile took 0.56-0.73 ms on the final layer and its transpose), and the conversion to
+// steps.
+constexpr int KTAB_SLICES = 128;
+__global__ void ktab_reset_kernel(int32_t* __restrict__ ktab, int nt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nt) { ktab[2 * i] = 0x7fffffff; ktab[2 * i + 1] = -1; }
+}
+
+__global__ __launch_bounds__(256) void ktab_scan_kernel(const float* __restrict__ mask, int out, int in, int src_rows,
+                                                        int32_t* __restrict__ ktab, int transposed) {
+    const int tn = blockIdx.x, slice = blockIdx.y, t = threadIdx.x;
     const int row0 = tn * src_rows;
     const int rows = min(src_rows, out - row0);
-    if (mask) {
-        for (int64_t i = threadIdx.x; i < (int64_t)rows * in; i += blockDim.x) {
-            const int r = (int)(i / in), k = (int)(i - (int64_t)r * in);
-            const int64_t at = transposed ? (int64_t)k * out + row0 + r : (int64_t)(row0 + r) * in + k;
-            if (mask[at] != 0.0f) { mylo = min(mylo, k); myhi = max(myhi, k); }
+    int lo = 0x7fffffff, hi = -1;
+    if (!mask) {
+        if (rows > 0 && slice == 0) { lo = 0; hi = in - 1; }
+    } else if (!transposed) {                      // mask[out][in]: threads along k
+        for (int r = slice; r < rows; r += KTAB_SLICES) {
+            const float* __restrict__ m = mask + (int64_t)(row0 + r) * in;
+#pragma unroll 4
+            for (int k = t; k < in; k += 256)
+                if (m[k] != 0.0f) { lo = min(lo, k); hi = max(hi, k); }
         }
-    } else if (rows > 0) {
-        mylo = 0;
-        myhi = in - 1;
+    } else {                                       // mask[in][out]: threads along the tile's rows
+        for (int k0 = slice; k0 < in; k0 += 8 * KTAB_SLICES) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * KTAB_SLICES;
+                for (int r = t; r < rows; r += 256)
+                    if (k < in && mask[(int64_t)k * out + row0 + r] != 0.0f) { lo = min(lo, k); hi = max(hi, k); }
+            }
+        }
     }
-    atomicMin(&lo, mylo);
-    atomicMax(&hi, myhi);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (hi < 0) { ktab[2 * tn] = 0; ktab[2 * tn + 1] = 0; }
-        else { ktab[2 * tn] = lo / 16; ktab[2 * tn + 1] = hi / 16 + 1; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, 64));
+        hi = max(hi, __shfl_xor(hi, off, 64));
     }
+    if ((t & 63) == 0 && hi >= 0) {
+        atomicMin(&ktab[2 * tn], lo);
+        atomicMax(&ktab[2 * tn + 1], hi);
+    }
+}
+
+__global__ void ktab_steps_kernel(int32_t* __restrict__ ktab, int nt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    const int lo = ktab[2 * i], hi = ktab[2 * i + 1];
+    if (hi < 0) { ktab[2 * i] = 0; ktab[2 * i + 1] = 0; }
+    else { ktab[2 * i] = lo / 16; ktab[2 * i + 1] = hi / 16 + 1; }
+}
+
+static void launch_ktab_fused(const float* mask, int out, int in, int src_rows, int nt, int32_t* ktab, int transposed,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(ktab_reset_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, ktab, nt);
+    hipLaunchKernelGGL(ktab_scan_kernel, dim3(nt, KTAB_SLICES), dim3(256), 0, s, mask, out, in, src_rows, ktab, transposed);
+    hipLaunchKernelGGL(ktab_steps_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, ktab, nt);
 }
 
 // ======================================================================================================
@@ -2108,7 +2142,7 @@ extern "C" int nf_made_rqs_pack_scaled(const float* W, const float* mask, const 
     else
         hipLaunchKernelGGL(pack_fused_kernel<__bf16>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, fpt * P, kpad,
                            total, P, 2 * K, logit_fold, (__bf16*)packed, bias_packed);
-    if (ktab) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, fpt * P, ktab, 0);
+    if (ktab) launch_ktab_fused(mask, out, in, fpt * P, nt, ktab, 0, s);
     return nf_launch_status();
 }
 
@@ -2278,7 +2312,7 @@ static int linear_split_pack_impl(const float* W, const float* mask, const float
         hipLaunchKernelGGL(pack_fused_split_kernel<SplitBf16x3>, dim3(grid), dim3(256), 0, s, W, mask, bias, out, in, FN,
                            kpad, total, 1, 0, 1.0f, (const unsigned*)nullptr, (__bf16*)packed, bias_packed, transposed);
     }
-    if (table) hipLaunchKernelGGL(ktab_fused_kernel, dim3(nt), dim3(256), 0, s, mask, out, in, FN, ktab, transposed);
+    if (table) launch_ktab_fused(mask, out, in, FN, nt, ktab, transposed, s);
     return nf_launch_status();
 }
 
