@@ -734,10 +734,17 @@ __device__ __forceinline__ void split_k_loop(const FusedArgs& g, char* lds, int6
         }
     }
     __syncthreads();
-    for (int kt = 0; kt < kn; kt += 2) {
+    // Steps in unconditional pairs, the odd last one after the loop: with the second step under an `if` inside the
+    // loop, the loop header had a predecessor in which the loads of the first step were the youngest ones, and hipcc's
+    // wait counts for the merged state drained nearly every outstanding load at the top of each iteration (vmcnt(1)
+    // in front of the first MFMA: a full memory latency per two steps, which is what the one-term flavour's 256-cycle
+    // steps were waiting on).
+    int kt = 0;
+    for (; kt + 1 < kn; kt += 2) {
         X3_STEP(0, 0, kt)
-        if (kt + 1 < kn) X3_STEP(NSET - 1, 1, kt + 1)
+        X3_STEP(NSET - 1, 1, kt + 1)
     }
+    if (kt < kn) X3_STEP(0, 0, kt)
 #undef KP
 #undef X3_STEP
 #undef X3_STORE_A
