@@ -168,6 +168,16 @@ int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, 
                     float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K,
                     int tails, double tail_bound, double min_bin_width, double min_bin_height,
                     double min_derivative, int inverse, int dtype, void* stream);
+/* nf_made_rqs_fwd (forward direction, NF_DTYPE_F32 / NF_DTYPE_BF16) that also KEEPS the conditioner output: params_out
+ * [B, features * P] as nf_masked_linear_fwd would have written it (made.py:358), logits unfolded with `logit_div` (the
+ * value given to nf_made_rqs_pack_scaled, 1 for nf_made_rqs_pack).  The training forward: nf_rqs_bwd recomputes from
+ * (x, params), and the parameters are not read back between the GEMM and the spline. */
+int nf_made_rqs_fwd_params(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                           const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                           int64_t y_row_stride, float* logabsdet, int accumulate, float* workspace,
+                           size_t workspace_bytes, int64_t B, int in, int features, int K, int tails,
+                           double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                           int dtype, double logit_div, float* params_out, int64_t params_row_stride, void* stream);
 
 /* Same, restricted to column tiles [tile_begin, tile_begin + tile_count) and to features < feat_limit
  * (later features of the last tile are neither read nor written); the per-tile logdet partial sums stay

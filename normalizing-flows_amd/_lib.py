@@ -144,6 +144,11 @@ _SIGNATURES = {
                                                _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
                                                _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double,
                                                _c.c_void_p]),
+    'nf_made_rqs_fwd_params': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                          _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                          _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_double,
+                                          _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_double, _c.c_void_p,
+                                          _c.c_int64, _c.c_void_p]),
     'nf_made_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -518,7 +523,9 @@ class PackedFusedFinal:
     """Device buffers of nf_made_rqs_pack: the final MADE layer regrouped to whole features per tile."""
     __slots__ = ('features', 'inp', 'K', 'tails', 'dtype', 'packed', 'ktab', 'bias', 'tiles')
 
-    def __init__(self, weight, mask, bias, features, num_bins, tails, dtype=NF_DTYPE_F32, logit_div=1.0):
+    def __init__(self, weight, mask, bias, features, num_bins, tails, dtype=NF_DTYPE_F32, logit_div=1.0, reuse=None):
+        """reuse: the previous pack of the same layer and spline shape with the same mask: its buffers are rewritten in
+        place and (f32 / bf16) its K-range table is kept - the per-optimizer-step path of training."""
         lib = load()
         w = _dev(weight.detach().contiguous(), 'weight')
         m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
@@ -528,13 +535,20 @@ class PackedFusedFinal:
         self.tiles = lib.nf_made_rqs_tiles(self.features, self.K, t)
         if self.tiles == 0:
             raise NfError(-2, 'nf_made_rqs_tiles')
-        self.packed = torch.empty(lib.nf_made_rqs_packed_bytes(self.features, self.inp, self.K, t, dtype),
-                                  dtype=torch.uint8, device=w.device)
-        self.ktab = torch.zeros(2 * self.tiles + 2, dtype=torch.int32, device=w.device)   # + the f16x2 scale pair
-        self.bias = torch.empty(256 * self.tiles, dtype=torch.float32, device=w.device)
+        fresh = reuse is None or reuse.packed.device != w.device or \
+            (reuse.features, reuse.inp, reuse.K, reuse.tails, reuse.dtype) != (self.features, self.inp, self.K, t, dtype)
+        if fresh:
+            self.packed = torch.empty(lib.nf_made_rqs_packed_bytes(self.features, self.inp, self.K, t, dtype),
+                                      dtype=torch.uint8, device=w.device)
+            self.ktab = torch.zeros(2 * self.tiles + 2, dtype=torch.int32, device=w.device)   # + the f16x2 scale pair
+            self.bias = torch.empty(256 * self.tiles, dtype=torch.float32, device=w.device)
+        else:
+            self.packed, self.ktab, self.bias = reuse.packed, reuse.ktab, reuse.bias
+        keep_table = not fresh and dtype in (NF_DTYPE_F32, NF_DTYPE_BF16)     # (f16x2 rewrites its scale pair there)
         with torch.cuda.device(w.device):
             _check(lib.nf_made_rqs_pack_scaled(w.data_ptr(), _ptr(m), _ptr(b), self.features, self.inp, self.K, t,
-                                               dtype, float(logit_div), self.packed.data_ptr(), self.ktab.data_ptr(),
+                                               dtype, float(logit_div), self.packed.data_ptr(),
+                                               None if keep_table else self.ktab.data_ptr(),
                                                self.bias.data_ptr(), _stream()), 'nf_made_rqs_pack')
 
 
@@ -619,6 +633,42 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
         _check(code, 'nf_made_rqs_fwd')
     tag_max(out, y_max)                 # (None outside the split-operand whole-layer launches)
     return out, logabsdet, bins
+
+
+def made_rqs_keeps_params(pf):
+    """Can the fused launch also write the conditioner output (nf_made_rqs_fwd_params)?  The f32 / bf16 kernel only."""
+    return pf.dtype in (NF_DTYPE_F32, NF_DTYPE_BF16)
+
+
+def made_rqs_params(h, pf, x, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, logit_div=1.0):
+    """The training forward of a whole autoregressive RQ layer: fused final MADE layer + spline that also KEEPS the
+    conditioner output (what the spline's backward recomputes from).  -> (y, logabsdet[B], params[B, features * P]).
+    `logit_div`: the value pf was packed with."""
+    lib = load()
+    _dev(h, 'hidden')
+    _dev(x, 'inputs')
+    B = x.shape[0]
+    hp, hs = _rows(h, 'hidden')
+    xp, xs = _rows(x, 'inputs')
+    if h.shape[0] != B or h.shape[1] != pf.inp or x.shape[1] != pf.features:
+        raise ValueError('Expected hidden [B,%d] and inputs [B,%d]' % (pf.inp, pf.features))
+    P = 3 * pf.K - 1 if pf.tails else 3 * pf.K + 1
+    out = torch.empty_like(x)
+    yp, ys = _rows(out, 'outputs')
+    logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
+    params = torch.empty((B, pf.features * P), dtype=torch.float32, device=x.device)
+    ws = fused_workspace(pf, B, x.device, planes=False)
+
+    def launch():
+        return lib.nf_made_rqs_fwd_params(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs,
+                                          yp, ys, logabsdet.data_ptr(), 0, ws.data_ptr(), ws.numel() * 4, B, pf.inp,
+                                          pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
+                                          float(min_bin_height), float(min_derivative), pf.dtype, float(logit_div),
+                                          params.data_ptr(), params.stride(0), _stream())
+    with torch.cuda.device(x.device):
+        code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * P, B), launch)
+        _check(code, 'nf_made_rqs_fwd_params')
+    return out, logabsdet, params
 
 
 FAMILY_CODE = {'linear': 1, 'quadratic': 2, 'cubic': 3}

@@ -56,35 +56,78 @@ class MaskedLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_y):
         (x,) = ctx.saved_tensors
-        layer = ctx.layer
         grad_y = grad_y.contiguous()
-        gx = gw = gb = None
-        split_y = _split_mode(grad_y, layer.out_features)
-        gy_max = _lib.tagged_max(grad_y)                   # left by the kernel that produced it (nf_rqs_bwd_max)
-        if split_y and gy_max is None:
-            gy_max = _lib.maxabs(grad_y)
-        if ctx.needs_input_grad[0]:
-            if split_y:
-                # dX = dY @ (W * mask): the same split-operand kernel on the transposed layer, ReLU gate in its epilogue
-                gx = _lib.masked_linear_split(grad_y, layer._packed_linear_split_t(), x_max=gy_max,
-                                              gate=x if ctx.relu_in else None, reverse_k=True)
-            else:
-                gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if ctx.relu_in else None)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            if _bf16_mode() and _lib.split_gemm_supported(grad_y, layer.out_features):
-                # bf16 mode: one scaled fp16 term per operand (11 bits against bf16's 8, same MFMA rate)
-                gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
-                                                             layer._wgrad_ktab(), ctx.relu_in, want_bias=ctx.has_bias,
-                                                             x_max=ctx.x_max, grad_y_max=gy_max, terms=1)
-            elif split_y and ctx.x_max is not None and _f16x2_mode():
-                gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
-                                                             layer._wgrad_ktab(), ctx.relu_in,
-                                                             want_bias=ctx.has_bias, x_max=ctx.x_max, grad_y_max=gy_max)
-            else:
-                gw, gb = _lib.masked_linear_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
-                                                       layer._wgrad_ktab(), ctx.relu_in, want_bias=ctx.has_bias)
+        gx, gw, gb = _linear_backward(ctx.layer, x, grad_y, ctx.relu_in, ctx.x_max, ctx.needs_input_grad[0],
+                                      ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]), ctx.has_bias)
         gres = grad_y if ctx.has_residual else None
         return gx, gw, gb, gres, None, None
+
+
+def _linear_backward(layer, x, grad_y, relu_in, x_max, want_x, want_w, has_bias):
+    """(grad_x, grad_W, grad_b) of y = act_in(x) @ (W*mask)^T + b from grad_y, in the current matrix mode."""
+    gx = gw = gb = None
+    split_y = _split_mode(grad_y, layer.out_features)
+    gy_max = _lib.tagged_max(grad_y)                   # left by the kernel that produced it (nf_rqs_bwd_max)
+    if split_y and gy_max is None:
+        gy_max = _lib.maxabs(grad_y)
+    if want_x:
+        if split_y:
+            # dX = dY @ (W * mask): the same split-operand kernel on the transposed layer, ReLU gate in its epilogue
+            gx = _lib.masked_linear_split(grad_y, layer._packed_linear_split_t(), x_max=gy_max,
+                                          gate=x if relu_in else None, reverse_k=True)
+        else:
+            gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if relu_in else None)
+    if want_w:
+        if _bf16_mode() and _lib.split_gemm_supported(grad_y, layer.out_features):
+            # bf16 mode: one scaled fp16 term per operand (11 bits against bf16's 8, same MFMA rate)
+            gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
+                                                         layer._wgrad_ktab(), relu_in, want_bias=has_bias,
+                                                         x_max=x_max, grad_y_max=gy_max, terms=1)
+        elif split_y and x_max is not None and _f16x2_mode():
+            gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
+                                                         layer._wgrad_ktab(), relu_in,
+                                                         want_bias=has_bias, x_max=x_max, grad_y_max=gy_max)
+        else:
+            gw, gb = _lib.masked_linear_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
+                                                   layer._wgrad_ktab(), relu_in, want_bias=has_bias)
+    return gx, gw, gb
+
+
+class FinalRqsFn(torch.autograd.Function):
+    """Final MADE layer + RQ spline of a whole autoregressive layer, forward direction, as ONE launch that also keeps the
+    conditioner output (nf_made_rqs_fwd_params): (y, logabsdet) = spline(x; hidden @ (W*mask)^T + b).  Backward: the
+    spline's backward kernel on the kept parameters, then the final layer's input / weight gradient GEMMs - what
+    MaskedLinearFn + RqsFn record as two nodes, minus one pass over the [B, D*P] parameter tensor."""
+
+    @staticmethod
+    def forward(ctx, x, hidden, weight, bias, layer, cfg):
+        num_bins, tails, tail_bound, mins = cfg
+        pf = layer._packed_fused_final(x.shape[1], num_bins, tails)
+        y, lad, params = _lib.made_rqs_params(hidden, pf, x, tail_bound, min_bin_width=mins[0], min_bin_height=mins[1],
+                                              min_derivative=mins[2])
+        ctx.save_for_backward(x, params, hidden)
+        ctx.layer, ctx.cfg, ctx.has_bias = layer, cfg, bias is not None
+        ctx.h_max = _lib.tagged_max(hidden)
+        return y, lad
+
+    @staticmethod
+    def backward(ctx, grad_y, grad_lad):
+        x, params, hidden = ctx.saved_tensors
+        num_bins, tails, tail_bound, mins = ctx.cfg
+        if grad_y is None:
+            grad_y = torch.zeros_like(x)
+        if grad_lad is None:
+            grad_lad = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
+        gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
+                                   min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2],
+                                   want_max=_f16x2_mode() or _bf16_mode())
+        h_max = ctx.h_max
+        if h_max is None and _bf16_mode():
+            h_max = _lib.maxabs(hidden)
+        gh, gw, gb = _linear_backward(ctx.layer, hidden, gparams, False, h_max, ctx.needs_input_grad[1],
+                                      ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]),
+                                      ctx.has_bias)
+        return gx, gh, gw, gb, None, None
 
 
 class RqsFn(torch.autograd.Function):

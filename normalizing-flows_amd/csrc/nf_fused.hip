@@ -75,6 +75,9 @@ struct FusedArgs {
     int64_t m_tiles;
     int group_m;             // row tiles that share a weight tile back to back (L2 reuse)
     int k_reverse;           // split GEMM: walk a tile's live K range from its end down (input-gradient launches)
+    float* params_out;       // made_rqs_kernel: nullable [M, D * P], the conditioner output a training forward keeps
+    int64_t ldp;
+    float unfold;            // ... whose logit columns are multiplied by this (the pack folded log2(e) / logit_div in)
     RqsConst c;
 };
 
@@ -247,7 +250,13 @@ __device__ __forceinline__ void drop_block(float* tile, int ncol, int wc, int la
     }
 }
 
-template <bool BF16, int KT, bool INV>
+// Barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access of the wave
+// (vmcnt(0)) - behind the parameter stores of a training forward that is a full drain of 128 KB per workgroup in front
+// of the spline evaluation they are meant to overlap with.
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// KEEP: the training forward - the parameters also go to g.params_out (see below)
+template <bool BF16, int KT, bool INV, bool KEEP = false>
 __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int fpt = g.fpt, P = g.c.P;
@@ -327,15 +336,46 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
         STAMP(tM)
     }
 
+    // training forward: the parameters (= the accumulators, bias included) also go to memory, straight from the MFMA
+    // layout - a lane's 16 values of a tile are 16 rows of ONE column, a store instruction writes two rows x 32
+    // consecutive columns.  They are issued here so that they drain under the spline evaluation below (whose barriers
+    // do not wait for them).  The pack folded log2(e) / logit_div into the logit rows: undone IN PLACE first (the
+    // evaluation below then takes natural-log logits) - a store's data register must not be rewritten while the store
+    // is in flight, so storing scaled temporaries made hipcc wait for every store before reusing them.
+    if (KEEP) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wc * 64 + j * 32 + (lane & 31);
+            const float uf = (col % P) < 2 * g.c.K ? g.unfold : 1.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= uf;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wc * 64 + j * 32 + (lane & 31);
+            if (col >= fv * P) continue;
+            float* pc = g.params_out + (int64_t)f0 * P + col;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + i * HR + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < g.M) pc[row * g.ldp] = acc[i][j][r];
+                }
+        }
+    }
+
     // ---- epilogue: the two 32-sample row blocks of the MFMA tiles, one after the other ---------------
     const int hrow = lane & 31, hsel = lane >> 5;    // eval: lane = sample row of the pass, two features per wave
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-        __syncthreads();                             // staging / previous pass fully consumed
+        lds_only_barrier();                          // staging / previous pass fully consumed
         STAMP(e0)
         if (half == 0) drop_block(tile, ncol, wc, lane, acc[0][0], acc[0][1]);
         else drop_block(tile, ncol, wc, lane, acc[1][0], acc[1][1]);
-        __syncthreads();
+        lds_only_barrier();
         STAMP(e1)
         float lsum = 0.f;
         const int r = half * HR + hrow;
@@ -346,7 +386,7 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
 #ifdef NF_KO_EPI
             yv = tile[e * P * LDT + hrow]; ld = yv; bin = 0;
 #else
-            rqs_eval<KT, INV, LDT, true, false, const float*, false>(tile + e * P * LDT + hrow, xs[r * fpt + e], g.c, yv, ld, bin);
+            rqs_eval<KT, INV, LDT, !KEEP, false, const float*, false>(tile + e * P * LDT + hrow, xs[r * fpt + e], g.c, yv, ld, bin);
 #endif
             xs[r * fpt + e] = yv;
             lsum += ld;
@@ -358,7 +398,7 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
         if (hsel == 0) ldp[wc * FM + r] = lsum;
         STAMP(e2)
     }
-    __syncthreads();
+    lds_only_barrier();
     if (tid < FM) {
         float s = 0.f;
 #pragma unroll
@@ -516,6 +556,9 @@ static void launch_ktab_fused(const float* mask, int out, int in, int src_rows, 
 #endif
 #ifndef NF_KO_EVAL
 #define NF_KO_EVAL 0
+#endif
+#ifndef NF_KO_OUT
+#define NF_KO_OUT 0
 #endif
 constexpr int XM = 128, XT = 256, XS = 16;     // samples per workgroup, threads, K elements per step
 // LDS stage = NT term planes of A [128 rows][32 B], rows unpadded; the two 16-byte halves of a row are
@@ -964,7 +1007,7 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
                         v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w;
                         if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     }
-                    if (row < g.M && c0 < g.N) {
+                    if (row < g.M && c0 < g.N && !(NF_KO_OUT && v.x != 12345.f)) {
                         *reinterpret_cast<float4*>(g.y + row * g.ldy + c0) = v;
                         const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
                         vmax = fmaxf(fmaxf(vmax, a0 < INFINITY ? a0 : 0.f), a1 < INFINITY ? a1 : 0.f);
@@ -2071,8 +2114,14 @@ inline size_t lds_bytes(int fpt, int P) {
 
 template <bool BF16, int KT, bool INV>
 int launch_one(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
-    static unsigned long long cap_done = 0;     // dynamic-LDS cap: once per instantiation and device
-    const int rc = nf_raise_lds_cap((const void*)made_rqs_kernel<BF16, KT, INV>, &cap_done);
+    static unsigned long long cap_done[2] = {0, 0};     // dynamic-LDS cap: once per instantiation and device
+    if (!INV && g.params_out) {
+        const int rc = nf_raise_lds_cap((const void*)made_rqs_kernel<BF16, KT, false, true>, &cap_done[1]);
+        if (rc != NF_OK) return rc;
+        hipLaunchKernelGGL((made_rqs_kernel<BF16, KT, false, true>), dim3(grid), dim3(FT), lds, s, g);
+        return nf_launch_status();
+    }
+    const int rc = nf_raise_lds_cap((const void*)made_rqs_kernel<BF16, KT, INV>, &cap_done[0]);
     if (rc != NF_OK) return rc;
     hipLaunchKernelGGL((made_rqs_kernel<BF16, KT, INV>), dim3(grid), dim3(FT), lds, s, g);
     return nf_launch_status();
@@ -2165,8 +2214,12 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
                           int features, int K, int tails, double tail_bound, double min_bin_width,
                           double min_bin_height, double min_derivative, int inverse, int dtype, int tile_begin,
                           int tile_count, int feat_limit, int reduce, const unsigned* h_max, unsigned* y_max,
-                          void* stream) {
+                          void* stream, float* params_out = nullptr, int64_t params_row_stride = 0,
+                          double logit_div = 1.0) {
     if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
+    if (params_out && (split_terms(dtype) || inverse || feat_index ||
+                       params_row_stride < (int64_t)features * (tails ? 3 * K - 1 : 3 * K + 1)))
+        return NF_ERR_LAYOUT;                       // (the f32 / bf16 forward kernel of whole autoregressive layers)
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
     if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && !split_terms(dtype)) return NF_ERR_DTYPE;
     if (y_max) {
@@ -2185,6 +2238,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
     g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max; g.vec_out = 0; g.k_reverse = 0;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
+    g.params_out = params_out; g.ldp = params_row_stride; g.unfold = (float)(logit_div * 0.6931471805599453);
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
     if (feat_limit > features || (tile_count > 0 && feat_limit <= (tile_begin + tile_count - 1) * g.fpt)) return NF_ERR_SHAPE;
@@ -2278,6 +2332,25 @@ extern "C" int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void*
                                  logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
                                  tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
                                  nf_made_rqs_tiles(features, K, tails), features, 1, stream);
+}
+
+// nf_made_rqs_fwd that also KEEPS the conditioner output: params[B, features * P] as nf_masked_linear_fwd would have
+// written it (logits unfolded with `logit_div`, the value given to nf_made_rqs_pack_scaled; 1 for nf_made_rqs_pack).
+// The training forward: one launch instead of GEMM + spline kernel, and `params` is not read back in between.
+// NF_DTYPE_F32 / NF_DTYPE_BF16, forward direction.
+extern "C" int nf_made_rqs_fwd_params(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                                      const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                                      int64_t y_row_stride, float* logabsdet, int accumulate, float* workspace,
+                                      size_t workspace_bytes, int64_t B, int in, int features, int K, int tails,
+                                      double tail_bound, double min_bin_width, double min_bin_height,
+                                      double min_derivative, int dtype, double logit_div, float* params_out,
+                                      int64_t params_row_stride, void* stream) {
+    if (!params_out) return NF_ERR_NULL;
+    return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr,
+                          features, logabsdet, accumulate, nullptr, workspace, workspace_bytes, B, in, features, K, tails,
+                          tail_bound, min_bin_width, min_bin_height, min_derivative, 0, dtype, 0,
+                          nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, nullptr, stream, params_out,
+                          params_row_stride, logit_div);
 }
 
 // ---- split-operand hidden-layer GEMM ------------------------------------------------------------------

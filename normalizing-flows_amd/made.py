@@ -129,12 +129,16 @@ class _PackedMixin:
 
     def _packed_fused_final(self, features, num_bins, tails, logit_div=1.0):
         """Final layer regrouped for the fused GEMM + spline kernel (nf_made_rqs_pack), cached likewise."""
+        mask = getattr(self, 'mask', None)
+        mkey = None if mask is None else (mask._version, mask.data_ptr())
         key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
-               get_matmul_dtype(), self.weight.device, features, num_bins, tails, float(logit_div))
+               get_matmul_dtype(), self.weight.device, features, num_bins, tails, float(logit_div), mkey)
         cached = getattr(self, '_fused_cache', None)
         if cached is None or cached[0] != key:
-            pf = _lib.PackedFusedFinal(self.weight, getattr(self, 'mask', None), self.bias, features, num_bins, tails,
-                                       _MATMUL_DTYPE[get_matmul_dtype()], logit_div=logit_div)
+            same = cached is not None and cached[0][3:] == key[3:]       # same mode, shape and mask: rewrite in place
+            pf = _lib.PackedFusedFinal(self.weight, mask, self.bias, features, num_bins, tails,
+                                       _MATMUL_DTYPE[get_matmul_dtype()], logit_div=logit_div,
+                                       reuse=cached[1] if same else None)
             object.__setattr__(self, '_fused_cache', (key, pf))
             cached = self._fused_cache
         return cached[1]

@@ -277,8 +277,19 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
     def _forward_autograd(self, inputs, context):
         """Training path: conditioner and spline as autograd.Functions over the backward kernels.  The
         parameter tensor is materialised here (the backward needs it); inference uses the fused kernel."""
-        params = self.autoregressive_net(inputs.contiguous(), context)      # context: extra GEMM + GLU gates (torch glue)
-        return self._elementwise_autograd(inputs.contiguous(), params, inverse=False)
+        net = self.autoregressive_net
+        inputs = inputs.contiguous()
+        if self._fusable() and made_module.get_matmul_dtype() in ('f32', 'bf16'):
+            # one launch for the final layer and the spline that also writes the parameters its backward recomputes
+            # from (nf_made_rqs_fwd_params): they are not read back between the GEMM and the spline
+            from .autograd import FinalRqsFn
+            final = net.final_layer
+            hidden = net.forward_hidden(inputs, context)
+            return FinalRqsFn.apply(inputs, hidden.contiguous(), final.weight, final.bias, final,
+                                    (self.num_bins, self.tails, self.tail_bound,
+                                     (self.min_bin_width, self.min_bin_height, self.min_derivative)))
+        params = net(inputs, context)      # context: extra GEMM + GLU gates (torch glue)
+        return self._elementwise_autograd(inputs, params, inverse=False)
 
     def _elementwise_autograd(self, inputs, params, inverse):
         from .autograd import RqsFn

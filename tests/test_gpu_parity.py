@@ -1269,6 +1269,34 @@ def test_training_gradients_match_autograd_of_the_oracle(nf, D, H, K, B):
             assert ((got - ref).abs().max().item() / scale) < 2e-3, (k, (got - ref).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize('mode,B,D,H,K', [('f32', 130, 40, 136, 4), ('f32', 64, 23, 64, 8), ('bf16', 200, 50, 128, 8),
+                                          ('f32', 1, 11, 8, 10)])
+def test_fused_forward_that_keeps_the_parameters(nf, mode, B, D, H, K):
+    """nf_made_rqs_fwd_params (the training forward: final MADE layer + spline in one launch, conditioner output kept):
+    params = the masked-linear kernel's output for the same layer (made.py:358), y / logabsdet = the fused launch
+    without the extra output; ragged row / feature tiles."""
+    from normalizing_flows_amd import _lib
+    nf.set_matmul_dtype(mode)
+    try:
+        sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=5, scale=0.3)
+        layer = _load_layers(nf, [sd], D, H, K, 3.0)[0].cuda()
+        net = layer.autoregressive_net
+        x = (torch.randn(B, D, generator=torch.Generator().manual_seed(B)) * 1.5).cuda()
+        with torch.no_grad():
+            hidden = net.forward_hidden(x).contiguous()
+            want_params = net.final_layer.fused(hidden)
+            pf = net.final_layer._packed_fused_final(D, K, 'linear')
+            want_y, want_lad, _ = _lib.made_rqs(hidden, pf, x, 3.0)
+            assert _lib.made_rqs_keeps_params(pf)
+            y, lad, params = _lib.made_rqs_params(hidden, pf, x, 3.0)
+        tol = 1e-5 if mode == 'f32' else 2e-2
+        assert _nerr(params, want_params) < tol, _nerr(params, want_params)
+        # the kept-parameters launch evaluates natural-log logits, the plain one base-2 folded ones: equal up to rounding
+        assert _nerr(y, want_y) < 1e-5 and _nerr(lad, want_lad) < 1e-5
+    finally:
+        nf.set_matmul_dtype('f32')
+
+
 @pytest.mark.parametrize('mode', ['f16x2', 'bf16x3'])
 def test_training_gradients_in_split_operand_modes(nf, mode):
     """The same gradient check with the forward and input-gradient GEMMs on the split-operand kernel (in f16x2
