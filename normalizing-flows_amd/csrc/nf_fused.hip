@@ -1291,7 +1291,7 @@ __global__ __launch_bounds__(256 * TW, 2 / TW) void wgrad_split_kernel(const Wgr
 // batch split and stays in L2.  A buffer = grad_y columns 0..127 + x columns 0..255 as two images (3 x 8 KB), double
 // buffered: 48 KB.
 constexpr int WT_IMG = 32 * 256;                   // bytes of one image
-constexpr int WT_N = 128, WT_K = 256;
+constexpr int WT_N = 128;                         // (input columns per tile: the kernel's template parameter WT_K)
 __device__ __forceinline__ int wt_off(int row, int ch) {     // byte offset of 16-byte chunk ch (0..15) of a row
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
@@ -1327,7 +1327,7 @@ __device__ __forceinline__ void wt_glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <bool XP>
+template <bool XP, int WT_K>
 __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef short s4 __attribute__((ext_vector_type(4)));
@@ -1381,7 +1381,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
     const float* ycol = g.gy + min(n0 + 4 * ycg, g.out - 4);
     const float* xcol = g.x + min(k0 + 4 * xcg, g.in - 4);
     // grad_y comes from HBM: three chunks of it in flight; x is the same for every workgroup of a batch split (L2): two
-    float4 cy[3][2], cx[XP ? 1 : 2][XL];
+    constexpr int NY = WT_K > 256 ? 2 : 3;           // (the 512-column tile has 128 accumulator registers: one set fewer)
+    float4 cy[NY][2], cx[XP ? 1 : 2][XL];
     auto load_y = [&](int c, int64_t b0) {
 #ifndef NF_WT_KO_LOADS
 #pragma unroll
@@ -1399,23 +1400,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
     };
     // XP: the chunk's NXI * 8 one-KB pieces (4 rows of an image each) are spread over the 8 waves, NXI per wave
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wt_lds;
-    const _Float16* xsrc[NXI];
-    int xrow[NXI];
-    unsigned xdst[NXI];
-#pragma unroll
-    for (int t = 0; t < NXI; ++t) {
-        const int piece = NXI * wave + t, img = piece >> 3, q = piece & 7;
-        const int row = 4 * q + (lane >> 4);
-        const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        xrow[t] = row;
-        xsrc[t] = g.xh + min(k0 + img * 128 + 8 * ch, g.in - 8);
-        xdst[t] = (unsigned)(2 * WT_IMG + img * WT_IMG + q * 1024);
-    }
+    // (addresses recomputed per piece: a handful of integer operations against 4 registers per piece held for the loop)
     auto dma_x = [&](int buf, int64_t b0) {
 #ifndef NF_WT_KO_LOADS
 #pragma unroll
-        for (int t = 0; t < NXI; ++t)
-            wt_glds16(xsrc[t] + min(b0 + xrow[t], b_end - 1) * g.ldxh, lds0 + xdst[t] + buf * NXI * WT_IMG);
+        for (int t = 0; t < NXI; ++t) {
+            const int piece = NXI * wave + t, img = piece >> 3, q = piece & 7;
+            const int row = 4 * q + (lane >> 4);
+            const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            wt_glds16(g.xh + min(k0 + img * 128 + 8 * ch, g.in - 8) + min(b0 + row, b_end - 1) * g.ldxh,
+                      lds0 + (unsigned)((2 + img + buf * NXI) * WT_IMG + q * 1024));
+        }
 #endif
     };
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};            // in grad_y's scaled units: this thread's four columns
@@ -1515,20 +1510,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
     if (XP) { dma_x(0, b_begin); dma_x(1, b_begin + WSB); }
     load_y(1, b_begin + WSB);
     load_x(1, b_begin + WSB);
-    load_y(2, b_begin + 2 * WSB);
+    if (NY == 3) load_y(2, b_begin + 2 * WSB);
     convert(0, 0, b_begin, 0);
     load_x(0, b_begin + 2 * WSB);
-    load_y(0, b_begin + 3 * WSB);
+    load_y(0, b_begin + NY * WSB);
     if (XP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #define WT_STEP(S_)                                                                       \
     {                                                                                     \
         const int64_t bs_ = b0 + (S_) * WSB;                                              \
         if (mma_first) { mma((S_) & 1, XP ? (S_) % 3 : (S_) & 1); __builtin_amdgcn_sched_barrier(0); } \
-        convert(((S_) + 1) % 3, ((S_) + 1) & 1, bs_ + WSB, ((S_) + 1) & 1);               \
+        convert(((S_) + 1) % NY, ((S_) + 1) & 1, bs_ + WSB, ((S_) + 1) & 1);              \
         if (XP) dma_x(((S_) + 2) % 3, bs_ + 2 * WSB);                                     \
         else load_x(((S_) + 1) & 1, bs_ + 3 * WSB);                                       \
-        load_y(((S_) + 1) % 3, bs_ + 4 * WSB);                                            \
+        load_y(((S_) + 1) % NY, bs_ + (1 + NY) * WSB);                                    \
         if (!mma_first) { __builtin_amdgcn_sched_barrier(0); mma((S_) & 1, XP ? (S_) % 3 : (S_) & 1); } \
         lds_barrier();                                                                    \
     }
@@ -2510,37 +2505,41 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
     if (terms == 1 && in % 4 == 0 && out % 4 == 0 && in >= 4 && out >= 4 && x_row_stride % 4 == 0 &&
         grad_y_row_stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad_y) & 15) == 0) {
         g.nt = (out + WT_N - 1) / WT_N;
-        g.kt = (in + WT_K - 1) / WT_K;
+        // a wide layer with a caller's workspace: x goes through its fp16 plane (every workgroup of a batch split
+        // re-reads the x chunk: half the bytes, no conversion in the loop); a layer of a few tiles reads x too
+        // rarely for the extra pass to pay.  (A 512-column tile - grad_y fetched once for this model's wide layers -
+        // was tried on top of the plane: 128 accumulator registers + the six unrolled steps' addresses spill 120
+        // bytes even with two grad_y sets, 1.41 ms against 1.07.)
+        const bool xp = workspace && (int64_t)g.nt * ((in + 255) / 256) > 128 && in % 8 == 0 &&
+                        ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (size_t)B * in * sizeof(_Float16);
+        const int wk = 256;
+        g.kt = (in + wk - 1) / wk;
         // batch splits: whole rounds of 256 workgroups (one per CU).  A wide layer takes about five (measured on
         // 18032 x 512: 2.01 / 1.57 / 1.40 / 1.40 / 1.43 ms at 1 / 2 / 4 / 5 / 8 rounds); a layer of a few tiles takes one:
         // each further round adds a full pass of fp32 atomics over grad_W (512 x 512: 71 / 101 / 130 us at 1 / 2 / 4)
         const int64_t tiles = (int64_t)g.nt * g.kt;
-        const int64_t target = tiles <= 128 ? 256 : 5 * 256;
+        const int64_t target = (int64_t)g.nt * ((in + 255) / 256) <= 128 ? 256 : 5 * 256;
         int64_t sp = (target + tiles / 2) / tiles;
         if (sp < 1) sp = 1;
         if (sp > max_splits) sp = max_splits;
         g.splits = (int)sp;
         g.group = g.kt * (32 / g.kt < 1 ? 1 : (32 / g.kt < g.nt ? 32 / g.kt : g.nt));
-        const int64_t wk = (int64_t)g.nt * g.kt * sp;
-        const int64_t gd = (wk + g.group - 1) / g.group * g.group;
+        const int64_t wkn = (int64_t)g.nt * g.kt * sp;
+        const int64_t gd = (wkn + g.group - 1) / g.group * g.group;
         const int64_t bk = (gd / g.group + 7) / 8 * 8 * g.group;
         if (bk > 0x7fffffff) return NF_ERR_SHAPE;
-        static unsigned long long tr_cap[2] = {0, 0};
-        // a wide layer with a caller's workspace: x goes through its fp16 plane (every workgroup of a batch split
-        // re-reads the x chunk: half the bytes, no conversion in the loop); a layer of a few tiles reads x too
-        // rarely for the extra pass to pay
-        if (workspace && tiles > 128 && in % 8 == 0 && ((uintptr_t)workspace & 15) == 0 &&
-            workspace_bytes >= (size_t)B * in * sizeof(_Float16)) {
+        static unsigned long long tr_cap[3] = {0, 0, 0};
+        if (xp) {
             g.xh = (const _Float16*)workspace; g.ldxh = in;
             const int64_t quads = B * (in / 4);
             hipLaunchKernelGGL(half_plane_kernel, dim3((unsigned)(quads / 256 < 4096 ? quads / 256 + 1 : 4096)), dim3(256), 0, s,
                                x, x_row_stride, B, in, g.x_max, relu_in, (_Float16*)workspace);
-            if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<true>, &tr_cap[1])) return e;
-            hipLaunchKernelGGL(wgrad_tr_kernel<true>, dim3((unsigned)bk), dim3(512), (2 + 3 * (WT_K / 128)) * WT_IMG, s, g);
+            if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<true, 256>, &tr_cap[1])) return e;
+            hipLaunchKernelGGL((wgrad_tr_kernel<true, 256>), dim3((unsigned)bk), dim3(512), (2 + 3 * 2) * WT_IMG, s, g);
             return nf_launch_status();
         }
-        if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<false>, &tr_cap[0])) return e;
-        hipLaunchKernelGGL(wgrad_tr_kernel<false>, dim3((unsigned)bk), dim3(512), 2 * (1 + WT_K / 128) * WT_IMG, s, g);
+        if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<false, 256>, &tr_cap[0])) return e;
+        hipLaunchKernelGGL((wgrad_tr_kernel<false, 256>), dim3((unsigned)bk), dim3(512), 2 * (1 + 2) * WT_IMG, s, g);
         return nf_launch_status();
     }
     if (terms == 2 && tw == 2) hipLaunchKernelGGL((wgrad_split_kernel<2, SplitF16x2>), gr, bl, lds, s, g);
