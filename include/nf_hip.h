@@ -396,6 +396,13 @@ int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, cons
                                       const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
                                       const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,
                                       int64_t B, int in, int out, int relu_in, void* stream);
+/* The same with a caller-owned `workspace` of at least 2 * B * in * 2 bytes (16-byte aligned): wide layers (more than
+ * 128 output tiles of 128 x 256) carry act(x) as two fp16 planes written there first and fetched by LDS-DMA. */
+int nf_masked_linear_split_bwd_weight_ws(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                         const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
+                                         const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,
+                                         int64_t B, int in, int out, int relu_in, void* workspace,
+                                         size_t workspace_bytes, void* stream);
 
 /* The same weight gradient with ONE scaled fp16 term per operand (11 significant bits relative to each tensor's largest
  * element, fp32 accumulation, a third of the MFMAs): what the bf16 training mode uses (BASELINE config 5 "bf16 MADE

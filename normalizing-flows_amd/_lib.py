@@ -109,6 +109,10 @@ _SIGNATURES = {
     'nf_masked_linear_split_bwd_weight': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                                       _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                       _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_masked_linear_split_bwd_weight_ws': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                                          _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                                          _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+                                                          _c.c_size_t, _c.c_void_p]),
     'nf_masked_linear_half_bwd_weight': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                                       _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                       _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t,
@@ -470,13 +474,14 @@ def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=Tru
     gb = torch.zeros(out, dtype=torch.float32, device=x.device) if want_bias else None
     m = None if mask is None else _dev(mask.contiguous(), 'mask')
     with torch.cuda.device(x.device):
+        # wide layers: act(x) as fp16 plane(s) in a workspace (the operand every workgroup re-reads, fetched by LDS-DMA)
+        ws = torch.empty(terms * B * inp * 2, dtype=torch.uint8, device=x.device) if out >= 2048 and inp % 8 == 0 else None
         if terms == 2:
-            _check(lib.nf_masked_linear_split_bwd_weight(xp, xs, x_max.data_ptr(), gp, gs, grad_y_max.data_ptr(), _ptr(m),
-                                                         _ptr(ktab), gw.data_ptr(), _ptr(gb), B, inp, out, int(relu_in),
-                                                         _stream()), 'nf_masked_linear_split_bwd_weight')
+            _check(lib.nf_masked_linear_split_bwd_weight_ws(xp, xs, x_max.data_ptr(), gp, gs, grad_y_max.data_ptr(), _ptr(m),
+                                                            _ptr(ktab), gw.data_ptr(), _ptr(gb), B, inp, out,
+                                                            int(relu_in), _ptr(ws), 0 if ws is None else ws.numel(),
+                                                            _stream()), 'nf_masked_linear_split_bwd_weight')
         else:
-            # wide layers: act(x) as an fp16 plane in a workspace (half the bytes of the operand every workgroup re-reads)
-            ws = torch.empty(B * inp * 2, dtype=torch.uint8, device=x.device) if out >= 2048 and inp % 8 == 0 else None
             _check(lib.nf_masked_linear_half_bwd_weight(xp, xs, x_max.data_ptr(), gp, gs, grad_y_max.data_ptr(), _ptr(m),
                                                         _ptr(ktab), gw.data_ptr(), _ptr(gb), B, inp, out, int(relu_in),
                                                         _ptr(ws), 0 if ws is None else ws.numel(), _stream()),

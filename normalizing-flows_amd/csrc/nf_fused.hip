@@ -1069,8 +1069,8 @@ struct WgradSplitArgs {
     float* gb;               // nullable: column sums of grad_y, accumulated by the tk == 0 blocks
     int64_t M;
     int out, in, relu_in, splits;
-    const _Float16* xh;      // wgrad_tr_kernel<true>: act(x) * 2^e as an fp16 plane [M][ldxh]
-    int64_t ldxh;
+    const _Float16* xh;      // wgrad_tr_kernel<true>: act(x) * 2^e as fp16 plane(s) [terms][M][ldxh]
+    int64_t ldxh, xh_plane;
     int nt, kt, group;       // tiles along out / in; consecutive work items kept on one XCD
 };
 
@@ -1301,6 +1301,8 @@ __device__ __forceinline__ int wt_off(int row, int ch) {     // byte offset of 1
 // fetches logical chunk position ^ swizzle(row)): half the bytes of the fp32 rows through L2 -> CU, which is what
 // bounds this kernel (every workgroup of a batch split re-reads the same x chunk), no staging registers and no
 // conversion work for x in the loop.  Three x buffers: the DMA of chunk s + 2 is issued in step s.
+// (NT = 2: the second plane, M * K elements further, holds the fp16 remainders of the first - the f16x2 operand split)
+template <int NT>
 __global__ __launch_bounds__(256) void half_plane_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int K,
                                                          const unsigned* __restrict__ x_max, int relu,
                                                          _Float16* __restrict__ plane) {
@@ -1314,8 +1316,14 @@ __global__ __launch_bounds__(256) void half_plane_kernel(const float* __restrict
         const int c = (int)(i - r * cpr) * 4;
         float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        const h4 hv = {(_Float16)(v.x * sx), (_Float16)(v.y * sx), (_Float16)(v.z * sx), (_Float16)(v.w * sx)};
+        v.x *= sx; v.y *= sx; v.z *= sx; v.w *= sx;
+        const h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         *reinterpret_cast<h4*>(plane + r * K + c) = hv;
+        if (NT == 2) {
+            const h4 lv = {(_Float16)(v.x - (float)hv[0]), (_Float16)(v.y - (float)hv[1]), (_Float16)(v.z - (float)hv[2]),
+                           (_Float16)(v.w - (float)hv[3])};
+            *reinterpret_cast<h4*>(plane + M * K + r * K + c) = lv;
+        }
     }
 }
 
@@ -1327,8 +1335,11 @@ __device__ __forceinline__ void wt_glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <bool XP, int WT_K>
+// NT = 2 (with the x planes only): the f16x2 flavour - two fp16 terms per operand, products hi*hi + hi*lo + lo*hi
+// (SplitF16x2's), twice the images, three MFMAs per product.
+template <bool XP, int WT_K, int NT = 1>
 __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g) {
+    static_assert(NT == 1 || XP, "two terms: x comes from its planes");
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef short s4 __attribute__((ext_vector_type(4)));
     typedef short s8 __attribute__((ext_vector_type(8)));
@@ -1337,10 +1348,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
     constexpr int XL = WT_K / 64;                    // 16-byte x loads per thread and chunk (fp32 rows)
     constexpr int XG = WT_K / 4;                     // four-column groups of an x row
     constexpr int NJ = WT_K / 128;                   // 32-column blocks of a wave along the input width
-    // LDS: XP ? [2 grad_y images][3 x buffers of NXI images] : [2 buffers of (grad_y image + NXI x images)]
+    // LDS: XP ? [2 buffers][NT] grad_y images, then [3 buffers][NT][NXI] x images
+    //         : [2 buffers of (grad_y image + NXI x images)]
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
-    auto ybase = [&](int buf) { return wt_lds + (XP ? buf * WT_IMG : buf * (1 + NXI) * WT_IMG); };
-    auto xbase = [&](int buf) { return wt_lds + (XP ? (2 + buf * NXI) * WT_IMG : (buf * (1 + NXI) + 1) * WT_IMG); };
+    auto ybase = [&](int buf) { return wt_lds + (XP ? buf * NT * WT_IMG : buf * (1 + NXI) * WT_IMG); };
+    auto xbase = [&](int buf) { return wt_lds + (XP ? (2 * NT + buf * NT * NXI) * WT_IMG : (buf * (1 + NXI) + 1) * WT_IMG); };
     const int slot = blockIdx.x >> 3;
     const int64_t w = ((int64_t)(slot / g.group) * 8 + (blockIdx.x & 7)) * g.group + slot % g.group;
     if (w >= (int64_t)g.nt * g.kt * g.splits) return;
@@ -1404,12 +1416,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
     auto dma_x = [&](int buf, int64_t b0) {
 #ifndef NF_WT_KO_LOADS
 #pragma unroll
-        for (int t = 0; t < NXI; ++t) {
-            const int piece = NXI * wave + t, img = piece >> 3, q = piece & 7;
+        for (int t = 0; t < NT * NXI; ++t) {
+            const int piece = NT * NXI * wave + t, term = piece / (8 * NXI), img = (piece >> 3) % NXI, q = piece & 7;
             const int row = 4 * q + (lane >> 4);
             const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-            wt_glds16(g.xh + min(k0 + img * 128 + 8 * ch, g.in - 8) + min(b0 + row, b_end - 1) * g.ldxh,
-                      lds0 + (unsigned)((2 + img + buf * NXI) * WT_IMG + q * 1024));
+            wt_glds16(g.xh + term * g.xh_plane + min(k0 + img * 128 + 8 * ch, g.in - 8) + min(b0 + row, b_end - 1) * g.ldxh,
+                      lds0 + (unsigned)((2 * NT + (buf * NT + term) * NXI + img) * WT_IMG + q * 1024));
         }
 #endif
     };
@@ -1425,6 +1437,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
             bsum[0] += v0; bsum[1] += v1; bsum[2] += v2; bsum[3] += v3;
             h4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
             *reinterpret_cast<h4*>(yb + wt_off(r, ycg >> 1) + 8 * (ycg & 1)) = hv;
+            if (NT == 2) {
+                h4 lv = {(_Float16)(v0 - (float)hv[0]), (_Float16)(v1 - (float)hv[1]), (_Float16)(v2 - (float)hv[2]),
+                         (_Float16)(v3 - (float)hv[3])};
+                *reinterpret_cast<h4*>(yb + WT_IMG + wt_off(r, ycg >> 1) + 8 * (ycg & 1)) = lv;
+            }
         }
         if (XP) return;
         char* xb = xbase(buf);
@@ -1464,34 +1481,43 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
         const char* xb = xbase(xbuf);
 #pragma unroll
         for (int ks = 0; ks < WSB / 16; ++ks) {
-            f16x8 a[2], b[NJ];
+            f16x8 a[2][NT], b[NJ][NT];
             // (rows + 16 ks: 4096 bytes further, the swizzle does not involve that bit)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const s4 lo = rd(yb, aoff[i][0] + 4096 * ks), hi = rd(yb, aoff[i][1] + 4096 * ks);
-                const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                a[i] = __builtin_bit_cast(f16x8, v);
-            }
+            for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const s4 lo = rd(xb, boff[j][0] + 4096 * ks), hi = rd(xb, boff[j][1] + 4096 * ks);
-                const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                b[j] = __builtin_bit_cast(f16x8, v);
+                for (int i = 0; i < 2; ++i) {
+                    const s4 lo = rd(yb, t * WT_IMG + aoff[i][0] + 4096 * ks), hi = rd(yb, t * WT_IMG + aoff[i][1] + 4096 * ks);
+                    const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    a[i][t] = __builtin_bit_cast(f16x8, v);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const s4 lo = rd(xb, t * NXI * WT_IMG + boff[j][0] + 4096 * ks);
+                    const s4 hi = rd(xb, t * NXI * WT_IMG + boff[j][1] + 4096 * ks);
+                    const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    b[j][t] = __builtin_bit_cast(f16x8, v);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) {
+                    if (NT == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][NT - 1], b[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][NT - 1], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
         }
 #endif
     };
     // the step barrier orders LDS traffic only: __syncthreads() would also drain vmcnt, i.e. wait out the chunks
     // requested steps ahead on purpose.  XP: the DMA pieces of chunk s + 1, which the next step reads, must have landed
-    // - after them this wave issued 2 grad_y loads in their own step (s - 1) and NXI + 2 operations in this one (loads return
+    // - after them this wave issued 2 grad_y loads in their own step (s - 1) and NT * NXI + 2 operations in this one (loads return
     // in order; hipcc's own counts for the grad_y registers only become stricter by the DMA operations it cannot see)
     auto lds_barrier = [] {
-        if (XP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NXI + 2) : "memory");
+        if (XP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NT * NXI + 2) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     // Waves w and w + 4 share a SIMD and take the two halves of a step - the MFMAs of chunk s (reads buffer s & 1) and
@@ -2478,7 +2504,7 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
     WgradSplitArgs g;
     g.x = x; g.ldx = x_row_stride; g.gy = grad_y; g.ldgy = grad_y_row_stride; g.x_max = (const unsigned*)x_max;
     g.gy_max = (const unsigned*)grad_y_max; g.mask = mask; g.ktab = ktab; g.gw = grad_w; g.gb = grad_b; g.M = B; g.out = out; g.in = in;
-    g.relu_in = relu_in; g.xh = nullptr; g.ldxh = 0;
+    g.relu_in = relu_in; g.xh = nullptr; g.ldxh = 0; g.xh_plane = 0;
     const int tw = out >= 2048 ? 2 : 1;                                  // wide layers: 256-row tiles, one workgroup per CU
     const int nt = (out + 128 * tw - 1) / (128 * tw), kt = (in + 127) / 128;
     int64_t splits = 3072 / tw / ((int64_t)nt * kt) + 1;
@@ -2501,17 +2527,21 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
     const size_t lds = (size_t)2 * terms * (128 * tw + 128) * WSLD * sizeof(_Float16);   // 2 buffers x terms
     const dim3 gr((unsigned)blocks), bl(256 * tw);
     hipStream_t s = (hipStream_t)stream;
-    // one term, everything 16-byte addressable: the transposed-read kernel (row-wise 16-byte fetches)
-    if (terms == 1 && in % 4 == 0 && out % 4 == 0 && in >= 4 && out >= 4 && x_row_stride % 4 == 0 &&
-        grad_y_row_stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad_y) & 15) == 0) {
+    // everything 16-byte addressable: the transposed-read kernel (row-wise 16-byte fetches) - one term always, two terms
+    // when x goes through its planes (wide layer + workspace)
+    const bool tr_ok = in % 4 == 0 && out % 4 == 0 && in >= 4 && out >= 4 && x_row_stride % 4 == 0 &&
+                       grad_y_row_stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad_y) & 15) == 0;
+    const bool planes_ok = workspace && (int64_t)((out + WT_N - 1) / WT_N) * ((in + 255) / 256) > 128 && in % 8 == 0 &&
+                           ((uintptr_t)workspace & 15) == 0 &&
+                           workspace_bytes >= (size_t)terms * (size_t)B * in * sizeof(_Float16);
+    if (tr_ok && (terms == 1 || planes_ok)) {
         g.nt = (out + WT_N - 1) / WT_N;
         // a wide layer with a caller's workspace: x goes through its fp16 plane (every workgroup of a batch split
         // re-reads the x chunk: half the bytes, no conversion in the loop); a layer of a few tiles reads x too
         // rarely for the extra pass to pay.  (A 512-column tile - grad_y fetched once for this model's wide layers -
         // was tried on top of the plane: 128 accumulator registers + the six unrolled steps' addresses spill 120
         // bytes even with two grad_y sets, 1.41 ms against 1.07.)
-        const bool xp = workspace && (int64_t)g.nt * ((in + 255) / 256) > 128 && in % 8 == 0 &&
-                        ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (size_t)B * in * sizeof(_Float16);
+        const bool xp = planes_ok;
         const int wk = 256;
         g.kt = (in + wk - 1) / wk;
         // batch splits: whole rounds of 256 workgroups (one per CU).  A wide layer takes about five (measured on
@@ -2530,10 +2560,18 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
         if (bk > 0x7fffffff) return NF_ERR_SHAPE;
         static unsigned long long tr_cap[3] = {0, 0, 0};
         if (xp) {
-            g.xh = (const _Float16*)workspace; g.ldxh = in;
+            g.xh = (const _Float16*)workspace; g.ldxh = in; g.xh_plane = B * in;
             const int64_t quads = B * (in / 4);
-            hipLaunchKernelGGL(half_plane_kernel, dim3((unsigned)(quads / 256 < 4096 ? quads / 256 + 1 : 4096)), dim3(256), 0, s,
-                               x, x_row_stride, B, in, g.x_max, relu_in, (_Float16*)workspace);
+            const dim3 pg((unsigned)(quads / 256 < 4096 ? quads / 256 + 1 : 4096));
+            if (terms == 2) {
+                hipLaunchKernelGGL(half_plane_kernel<2>, pg, dim3(256), 0, s, x, x_row_stride, B, in, g.x_max, relu_in,
+                                   (_Float16*)workspace);
+                if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<true, 256, 2>, &tr_cap[2])) return e;
+                hipLaunchKernelGGL((wgrad_tr_kernel<true, 256, 2>), dim3((unsigned)bk), dim3(512), (4 + 3 * 4) * WT_IMG, s, g);
+                return nf_launch_status();
+            }
+            hipLaunchKernelGGL(half_plane_kernel<1>, pg, dim3(256), 0, s, x, x_row_stride, B, in, g.x_max, relu_in,
+                               (_Float16*)workspace);
             if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<true, 256>, &tr_cap[1])) return e;
             hipLaunchKernelGGL((wgrad_tr_kernel<true, 256>), dim3((unsigned)bk), dim3(512), (2 + 3 * 2) * WT_IMG, s, g);
             return nf_launch_status();
@@ -2578,6 +2616,17 @@ extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_s
                                                  void* stream) {
     return wgrad_split_impl(x, x_row_stride, x_max, grad_y, grad_y_row_stride, grad_y_max, mask, ktab, grad_w, grad_b, B,
                             in, out, relu_in, 2, stream);
+}
+
+// The same with a caller-owned workspace (2 * B * in * 2 bytes, 16-byte aligned): wide layers (more than 128 output
+// tiles of 128 x 256) then run the transposed-read kernel with act(x) pre-split into two fp16 planes fetched by LDS-DMA.
+extern "C" int nf_masked_linear_split_bwd_weight_ws(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                                    const float* grad_y, int64_t grad_y_row_stride,
+                                                    const uint32_t* grad_y_max, const float* mask, const int32_t* ktab,
+                                                    float* grad_w, float* grad_b, int64_t B, int in, int out,
+                                                    int relu_in, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_split_impl(x, x_row_stride, x_max, grad_y, grad_y_row_stride, grad_y_max, mask, ktab, grad_w, grad_b, B,
+                            in, out, relu_in, 2, stream, workspace, workspace_bytes);
 }
 
 // The same weight gradient with ONE scaled fp16 term per operand (11 significant bits relative to each tensor's

@@ -1314,7 +1314,9 @@ def test_training_gradients_in_split_operand_modes(nf, mode):
 @pytest.mark.parametrize('B,inp,out,relu_in,masked,bias', [
     (130, 40, 136, True, True, True), (4096, 256, 384, False, True, True), (37, 8, 8, True, False, False),
     (20000, 128, 392, True, True, True), (1, 16, 24, False, False, True), (1500, 136, 2300, True, True, True),
-    (333, 264, 2048, False, False, True)])
+    (333, 264, 2048, False, False, True),
+    # more than 128 output tiles: the transposed-read kernel with act(x) as two fp16 planes (workspace, LDS-DMA)
+    (700, 512, 9000, True, True, True), (333, 264, 16500, False, True, True), (4100, 520, 9100, True, False, False)])
 def test_split_operand_weight_gradient(nf, B, inp, out, relu_in, masked, bias):
     """nf_masked_linear_split_bwd_weight (two fp16 terms per operand, fp32 accumulate) against float64 torch:
     grad_W = mask * grad_y^T @ act(x), grad_b = column sums; ragged tiles, batch tails, masked tiles skipped
