@@ -396,8 +396,9 @@ int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, cons
                                       const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
                                       const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,
                                       int64_t B, int in, int out, int relu_in, void* stream);
-/* The same with a caller-owned `workspace` of at least 2 * B * in * 2 bytes (16-byte aligned): wide layers (more than
- * 128 output tiles of 128 x 256) carry act(x) as two fp16 planes written there first and fetched by LDS-DMA. */
+/* The same with a caller-owned `workspace` of at least 2 * B * in * 2 bytes (16-byte aligned; in % 8 == 0, 16-byte
+ * aligned rows): act(x) is written there first as two fp16 planes and fetched by LDS-DMA into the transposed-read
+ * kernel (row-wise 16-byte fetches of grad_y, ds_read_b64_tr_b16 operand reads). */
 int nf_masked_linear_split_bwd_weight_ws(const float* x, int64_t x_row_stride, const uint32_t* x_max,
                                          const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
                                          const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,

@@ -2531,7 +2531,7 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
     // when x goes through its planes (wide layer + workspace)
     const bool tr_ok = in % 4 == 0 && out % 4 == 0 && in >= 4 && out >= 4 && x_row_stride % 4 == 0 &&
                        grad_y_row_stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)grad_y) & 15) == 0;
-    const bool planes_ok = workspace && (int64_t)((out + WT_N - 1) / WT_N) * ((in + 255) / 256) > 128 && in % 8 == 0 &&
+    const bool planes_ok = workspace && (terms == 2 || (int64_t)((out + WT_N - 1) / WT_N) * ((in + 255) / 256) > 128) && in % 8 == 0 &&
                            ((uintptr_t)workspace & 15) == 0 &&
                            workspace_bytes >= (size_t)terms * (size_t)B * in * sizeof(_Float16);
     if (tr_ok && (terms == 1 || planes_ok)) {
@@ -2618,8 +2618,8 @@ extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_s
                             in, out, relu_in, 2, stream);
 }
 
-// The same with a caller-owned workspace (2 * B * in * 2 bytes, 16-byte aligned): wide layers (more than 128 output
-// tiles of 128 x 256) then run the transposed-read kernel with act(x) pre-split into two fp16 planes fetched by LDS-DMA.
+// The same with a caller-owned workspace (2 * B * in * 2 bytes, 16-byte aligned): the transposed-read kernel with act(x)
+// pre-split into two fp16 planes fetched by LDS-DMA.
 extern "C" int nf_masked_linear_split_bwd_weight_ws(const float* x, int64_t x_row_stride, const uint32_t* x_max,
                                                     const float* grad_y, int64_t grad_y_row_stride,
                                                     const uint32_t* grad_y_max, const float* mask, const int32_t* ktab,
