@@ -638,30 +638,51 @@ __global__ void pack_bf16_kernel(const float* __restrict__ W, const float* __res
     }
 }
 
+// K-tile table: [tile][first, one-past-last 32-wide K tile with an unmasked weight].  A function of the mask only.
+// KTAB_SLICES workgroups per tile scan it (consecutive threads on consecutive addresses when the fast index has unit
+// stride), raw column bounds meet in the table through atomics, a last launch converts them to tiles.
+constexpr int KTAB_SLICES = 64;
+__global__ void ktab_reset_kernel(int32_t* __restrict__ ktab, int nt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nt) { ktab[2 * i] = 0x7fffffff; ktab[2 * i + 1] = -1; }
+}
+
 __global__ __launch_bounds__(256) void ktab_kernel(const float* __restrict__ mask, int out, int in, int64_t sn,
                                                    int64_t sk, int32_t* __restrict__ ktab) {
-    __shared__ int lo, hi;
-    const int tn = blockIdx.x;
-    if (threadIdx.x == 0) { lo = 0x7fffffff; hi = -1; }
-    __syncthreads();
-    int mylo = 0x7fffffff, myhi = -1;
-    if (mask) {
-        const int rows = min(BN, out - tn * BN);
-        for (int64_t i = threadIdx.x; i < (int64_t)rows * in; i += blockDim.x) {
-            const int r = (int)(i / in), k = (int)(i - (int64_t)r * in);
-            if (mask[(int64_t)(tn * BN + r) * sn + k * sk] != 0.0f) { mylo = min(mylo, k); myhi = max(myhi, k); }
+    const int tn = blockIdx.x, slice = blockIdx.y, t = threadIdx.x;
+    const int rows = min(BN, out - tn * BN);
+    int lo = 0x7fffffff, hi = -1;
+    if (!mask) {
+        if (rows > 0 && slice == 0) { lo = 0; hi = in - 1; }
+    } else if (sk == 1) {                          // rows of the logical matrix are contiguous: threads along k
+        for (int r = slice; r < rows; r += KTAB_SLICES) {
+            const float* __restrict__ m = mask + (int64_t)(tn * BN + r) * sn;
+#pragma unroll 4
+            for (int k = t; k < in; k += 256)
+                if (m[k] != 0.0f) { lo = min(lo, k); hi = max(hi, k); }
         }
-    } else {
-        mylo = 0;
-        myhi = in - 1;
+    } else {                                       // transposed view: threads along the tile's rows
+        for (int k = slice; k < in; k += KTAB_SLICES)
+            for (int r = t; r < rows; r += 256)
+                if (mask[(int64_t)(tn * BN + r) * sn + k * sk] != 0.0f) { lo = min(lo, k); hi = max(hi, k); }
     }
-    atomicMin(&lo, mylo);
-    atomicMax(&hi, myhi);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (hi < 0) { ktab[2 * tn] = 0; ktab[2 * tn + 1] = 0; }
-        else { ktab[2 * tn] = lo / BK; ktab[2 * tn + 1] = hi / BK + 1; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, 64));
+        hi = max(hi, __shfl_xor(hi, off, 64));
     }
+    if ((t & 63) == 0 && hi >= 0) {
+        atomicMin(&ktab[2 * tn], lo);
+        atomicMax(&ktab[2 * tn + 1], hi);
+    }
+}
+
+__global__ void ktab_tiles_kernel(int32_t* __restrict__ ktab, int nt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    const int lo = ktab[2 * i], hi = ktab[2 * i + 1];
+    if (hi < 0) { ktab[2 * i] = 0; ktab[2 * i + 1] = 0; }
+    else { ktab[2 * i] = lo / BK; ktab[2 * i + 1] = hi / BK + 1; }
 }
 
 inline int n_tiles_of(int out) { return (out + BN - 1) / BN; }
@@ -692,7 +713,12 @@ static int pack_impl(const float* W, const float* mask, int out, int in, int64_t
     else
         hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, s, W, mask, out, in, sn, sk, kpad, total,
                            (__bf16*)packed);
-    if (ktab) hipLaunchKernelGGL(ktab_kernel, dim3(n_tiles_of(out)), dim3(256), 0, s, mask, out, in, sn, sk, ktab);
+    if (ktab) {
+        const int nt = n_tiles_of(out);
+        hipLaunchKernelGGL(ktab_reset_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, ktab, nt);
+        hipLaunchKernelGGL(ktab_kernel, dim3(nt, KTAB_SLICES), dim3(256), 0, s, mask, out, in, sn, sk, ktab);
+        hipLaunchKernelGGL(ktab_tiles_kernel, dim3((nt + 255) / 256), dim3(256), 0, s, ktab, nt);
+    }
     return nf_launch_status();
 }
 
