@@ -414,6 +414,27 @@ int nf_masked_linear_half_bwd_weight(const float* x, int64_t x_row_stride, const
                                      const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
                                      const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,
                                      int64_t B, int in, int out, int relu_in, void* stream);
+/* The bf16 training mode's gradient plane.  The parameter gradients of an autoregressive RQ layer have exactly two
+ * readers, the final layer's backward GEMMs, which round them to bf16 / fp16: nf_rqs_bwd_max_bf16 writes them as a bf16
+ * matrix [B, D*P] (8-byte aligned; everything else as nf_rqs_bwd_max, the slot gets max |gradient| before rounding),
+ * nf_masked_linear_split_bwd_input_bf16 is nf_masked_linear_split_bwd_input (NF_DTYPE_BF16 pack) with that matrix as
+ * its A operand (row stride in elements, out % 16 == 0), nf_masked_linear_half_bwd_weight_bf16 is
+ * nf_masked_linear_half_bwd_weight with it as grad_y (wide layers with a workspace only, else NF_ERR_LAYOUT).
+ * No reference counterpart beyond autograd through made.py:358 + transforms.py:819-860. */
+int nf_rqs_bwd_max_bf16(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                        double pre_div, const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
+                        float* grad_x, int64_t grad_x_row_stride, void* grad_params_bf16, uint32_t* grad_params_max,
+                        int64_t B, int D, int K, int tails, double tail_bound, double min_bin_width,
+                        double min_bin_height, double min_derivative, int inverse, void* stream);
+int nf_masked_linear_split_bwd_input_bf16(const void* grad_y_bf16, int64_t grad_y_row_stride, const void* packed_wt,
+                                          const int32_t* ktab_t, const float* bias_zero, const float* gate,
+                                          int64_t gate_row_stride, float* grad_x, int64_t grad_x_row_stride,
+                                          uint32_t* grad_x_max, int64_t B, int out, int in, void* stream);
+int nf_masked_linear_half_bwd_weight_bf16(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                          const void* grad_y_bf16, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
+                                          const float* mask, const int32_t* ktab, float* grad_w, float* grad_b,
+                                          int64_t B, int in, int out, int relu_in, void* workspace,
+                                          size_t workspace_bytes, void* stream);
 /* Backward of nf_affine_fwd (either direction; replaces autograd through transforms.py:540-566 / :323-347): from x,
  * params (scale recomputed), grad_y[B, x columns] and grad_logabsdet[B] (nullable = 0) to grad_x (written at the D
  * transformed columns only; with feat_index the caller owns the identity columns) and grad_params[B, 2D] in the

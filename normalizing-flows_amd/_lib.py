@@ -109,6 +109,17 @@ _SIGNATURES = {
     'nf_masked_linear_split_bwd_weight': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                                       _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                       _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_rqs_bwd_max_bf16': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p,
+                                       _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p,
+                                       _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double,
+                                       _c.c_double, _c.c_int, _c.c_void_p]),
+    'nf_masked_linear_split_bwd_input_bf16': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                                         _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p,
+                                                         _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_masked_linear_half_bwd_weight_bf16': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                                         _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                                         _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
+                                                         _c.c_size_t, _c.c_void_p]),
     'nf_masked_linear_split_bwd_weight_ws': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                                           _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                           _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p,
@@ -492,10 +503,71 @@ def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=Tru
     return gw, gb
 
 
+# Test knob: False sends the bf16 mode's parameter gradients through the fp32 tensor again (same operand rounding in the
+# GEMMs, so the two settings must agree to fp32 summation order: tests/test_gpu_parity.py compares them).
+BF16_GRADIENT_PLANE = True
+
+
+def bf16_gradient_path(inp, out):
+    """Does the final layer [out, inp] take its output gradient as a bf16 matrix in both backward GEMMs
+    (nf_masked_linear_split_bwd_input_bf16: whole 16-wide K steps; nf_masked_linear_half_bwd_weight_bf16: the wide-layer
+    workspace path)?"""
+    if not BF16_GRADIENT_PLANE:
+        return False
+    return out % 16 == 0 and inp % 8 == 0 and ((out + 127) // 128) * ((inp + 255) // 256) > 128
+
+
+def masked_linear_split_bwd_input_bf16(grad_y16, pls, gate=None):
+    """grad_x = grad_y @ (W * mask) with grad_y a torch.bfloat16 matrix, pls the transposed NF_DTYPE_BF16 pack."""
+    lib = load()
+    if grad_y16.dtype != torch.bfloat16 or not grad_y16.is_cuda or grad_y16.stride(1) != 1:
+        raise TypeError('grad_y must be a CUDA bfloat16 matrix with contiguous rows')
+    if pls.dtype != NF_DTYPE_BF16 or grad_y16.shape[1] != pls.inp:
+        raise ValueError('expected the transposed bf16 pack of a layer with %d outputs' % grad_y16.shape[1])
+    B = grad_y16.shape[0]
+    gx = torch.empty((B, pls.out), dtype=torch.float32, device=grad_y16.device)
+    xp, xs = _rows(gx, 'grad_x')
+    tp, ts = (None, 0) if gate is None else _rows(_dev(gate, 'gate'), 'gate')
+    y_max = torch.empty(1, dtype=torch.int32, device=grad_y16.device)
+    with torch.cuda.device(grad_y16.device):
+        _check(lib.nf_masked_linear_split_bwd_input_bf16(grad_y16.data_ptr(), grad_y16.stride(0), pls.packed.data_ptr(),
+                                                         pls.ktab.data_ptr(), pls.bias.data_ptr(), tp, ts, xp, xs,
+                                                         y_max.data_ptr(), B, pls.inp, pls.out, _stream()),
+               'nf_masked_linear_split_bwd_input_bf16')
+    tag_max(gx, y_max)
+    return gx
+
+
+def masked_linear_half_bwd_weight_bf16(x, grad_y16, mask, ktab, relu_in, want_bias=True, x_max=None, grad_y_max=None):
+    """The one-term weight gradient with grad_y a torch.bfloat16 matrix (its max slot is required: the bf16 tensor's tag)."""
+    lib = load()
+    _dev(x, 'x')
+    if grad_y16.dtype != torch.bfloat16 or not grad_y16.is_cuda or grad_y16.stride(1) != 1:
+        raise TypeError('grad_y must be a CUDA bfloat16 matrix with contiguous rows')
+    if grad_y_max is None:
+        raise ValueError('grad_y_max: the slot nf_rqs_bwd_max_bf16 left')
+    xp, xs = _rows(x, 'x')
+    B, inp = x.shape
+    out = grad_y16.shape[1]
+    m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
+    x_max = maxabs(x) if x_max is None else x_max
+    gw = torch.zeros((out, inp), dtype=torch.float32, device=x.device)
+    gb = torch.zeros(out, dtype=torch.float32, device=x.device) if want_bias else None
+    ws = torch.empty(B * inp * 2, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.nf_masked_linear_half_bwd_weight_bf16(xp, xs, x_max.data_ptr(), grad_y16.data_ptr(), grad_y16.stride(0),
+                                                         grad_y_max.data_ptr(), _ptr(m), _ptr(ktab), gw.data_ptr(),
+                                                         _ptr(gb), B, inp, out, int(relu_in), ws.data_ptr(), ws.numel(),
+                                                         _stream()), 'nf_masked_linear_half_bwd_weight_bf16')
+    return gw, gb
+
+
 def rqs_bwd(x, params, grad_y, grad_lad, num_bins, tails, tail_bound, pre_div=1.0, min_bin_width=1e-3,
-            min_bin_height=1e-3, min_derivative=1e-3, inverse=False, want_max=False):
+            min_bin_height=1e-3, min_derivative=1e-3, inverse=False, want_max=False, bf16_out=False):
     """(grad wrt the spline's input, grad_params).  inverse: backward of the inverse direction - `x` is then that
-    pass's OUTPUT and grad_y the gradient wrt it (nf_rqs_inverse_bwd)."""
+    pass's OUTPUT and grad_y the gradient wrt it (nf_rqs_inverse_bwd).  bf16_out: grad_params come back as a
+    torch.bfloat16 tensor tagged with max |gradient| (nf_rqs_bwd_max_bf16) - for a caller that feeds them to the bf16
+    backward GEMMs and nowhere else."""
     lib = load()
     for t, n in ((x, 'inputs'), (params, 'params'), (grad_y, 'grad_y'), (grad_lad, 'grad_logabsdet')):
         _dev(t, n)
@@ -505,8 +577,19 @@ def rqs_bwd(x, params, grad_y, grad_lad, num_bins, tails, tail_bound, pre_div=1.
     gyp, gys = _rows(grad_y, 'grad_y')
     gx = torch.empty((B, D), dtype=torch.float32, device=x.device)
     gxp, gxs = _rows(gx, 'grad_x')
-    gparams = torch.empty_like(params)
     gl = grad_lad.contiguous()
+    if bf16_out:
+        gparams = torch.empty(params.shape, dtype=torch.bfloat16, device=x.device)
+        slot = torch.empty(1, dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            _check(lib.nf_rqs_bwd_max_bf16(xp, xs, pp, ps, float(pre_div), gyp, gys, gl.data_ptr(), gxp, gxs,
+                                           gparams.data_ptr(), slot.data_ptr(), B, D, int(num_bins),
+                                           1 if tails == 'linear' else 0, float(tail_bound), float(min_bin_width),
+                                           float(min_bin_height), float(min_derivative), int(inverse), _stream()),
+                   'nf_rqs_bwd_max_bf16')
+        tag_max(gparams, slot)
+        return gx, gparams
+    gparams = torch.empty_like(params)
     with torch.cuda.device(x.device):
         if want_max:
             # the kernel leaves max |grad_params| in a slot and the gradient carries it as a tag: the f16x2 GEMMs of

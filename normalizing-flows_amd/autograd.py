@@ -118,12 +118,28 @@ class FinalRqsFn(torch.autograd.Function):
             grad_y = torch.zeros_like(x)
         if grad_lad is None:
             grad_lad = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
-        gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
-                                   min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2],
-                                   want_max=_f16x2_mode() or _bf16_mode())
+        layer = ctx.layer
         h_max = ctx.h_max
         if h_max is None and _bf16_mode():
             h_max = _lib.maxabs(hidden)
+        if _bf16_mode() and _lib.bf16_gradient_path(layer.in_features, layer.out_features):
+            # bf16 mode: the parameter gradients never leave this node and both GEMMs below round them to bf16 (the
+            # weight gradient: to fp16) anyway - the spline backward writes them as bf16 (half the bytes written and
+            # re-read twice), the input gradient takes the plane as its A operand, the weight gradient widens it
+            gx, gp16 = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
+                                    min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2],
+                                    bf16_out=True)
+            gh = gw = gb = None
+            if ctx.needs_input_grad[1]:
+                gh = _lib.masked_linear_split_bwd_input_bf16(gp16, layer._packed_linear_split_t())
+            if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+                gw, gb = _lib.masked_linear_half_bwd_weight_bf16(hidden, gp16, getattr(layer, 'mask', None),
+                                                                 layer._wgrad_ktab(), False, want_bias=ctx.has_bias,
+                                                                 x_max=h_max, grad_y_max=_lib.tagged_max(gp16))
+            return gx, gh, gw, gb, None, None
+        gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
+                                   min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2],
+                                   want_max=_f16x2_mode() or _bf16_mode())
         gh, gw, gb = _linear_backward(ctx.layer, hidden, gparams, False, h_max, ctx.needs_input_grad[1],
                                       ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]),
                                       ctx.has_bias)

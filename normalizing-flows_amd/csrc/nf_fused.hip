@@ -952,7 +952,8 @@ __global__ __launch_bounds__(XT, 2) void made_rqs_split_kernel(const FusedArgs g
 // Hidden-layer GEMM on split operands: y = [relu](x) @ (W * mask)^T + b (+ residual) [relu], fp32 in and out,
 // 128 x 256 output tiles through the same K loop.  The largest |y| goes to g.out_max (the next layer's operand
 // scale comes from it, so chained layers need no pass over their input).
-template <class SP, bool RELU>
+// PRE: the A operand comes from term plane(s) g.hp ([terms][M][hp_ld], already in the operand type) instead of g.h.
+template <class SP, bool RELU, bool PRE = false>
 __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int64_t tm;
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
         pow2_pair(*g.hmax, hs, hi);
     }
     f32x16 acc[4][2];
-    split_k_loop<SP, false, RELU>(g, lds, m0, tn, tid, ws * hs, hs, acc);
+    split_k_loop<SP, PRE, RELU>(g, lds, m0, tn, tid, ws * hs, hs, acc);
     const float oscale = wi * hi;
     float vmax = 0.f;
     if (g.vec_out) {
@@ -1337,7 +1338,8 @@ __device__ __forceinline__ void wt_glds16(const void* gsrc, unsigned lds_dst) {
 
 // NT = 2 (with the x planes only): the f16x2 flavour - two fp16 terms per operand, products hi*hi + hi*lo + lo*hi
 // (SplitF16x2's), twice the images, three MFMAs per product.
-template <bool XP, int WT_K, int NT = 1>
+// YB: grad_y is a bf16 matrix [M][ldgy] (nf_rqs_bwd_max_bf16's output): 8-byte fetches, widened in the conversion step.
+template <bool XP, int WT_K, int NT = 1, bool YB = false>
 __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g) {
     static_assert(NT == 1 || XP, "two terms: x comes from its planes");
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -1391,15 +1393,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
     // vmcnt(0) at each use.
     const int ycg = tid & 31, yr0 = tid >> 5, xcg = tid % XG, xr0 = tid / XG;
     const float* ycol = g.gy + min(n0 + 4 * ycg, g.out - 4);
+    const __bf16* ycol16 = reinterpret_cast<const __bf16*>(g.gy) + min(n0 + 4 * ycg, g.out - 4);
     const float* xcol = g.x + min(k0 + 4 * xcg, g.in - 4);
     // grad_y comes from HBM: three chunks of it in flight; x is the same for every workgroup of a batch split (L2): two
     constexpr int NY = WT_K > 256 ? 2 : 3;           // (the 512-column tile has 128 accumulator registers: one set fewer)
-    float4 cy[NY][2], cx[XP ? 1 : 2][XL];
+    float4 cy[YB ? 1 : NY][2], cx[XP ? 1 : 2][XL];
+    uint2 cyb[YB ? NY : 1][2];
     auto load_y = [&](int c, int64_t b0) {
 #ifndef NF_WT_KO_LOADS
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-            cy[c][e] = *reinterpret_cast<const float4*>(ycol + min(b0 + yr0 + 16 * e, b_end - 1) * g.ldgy);
+        for (int e = 0; e < 2; ++e) {
+            if (YB) cyb[c][e] = *reinterpret_cast<const uint2*>(ycol16 + min(b0 + yr0 + 16 * e, b_end - 1) * g.ldgy);
+            else cy[c][e] = *reinterpret_cast<const float4*>(ycol + min(b0 + yr0 + 16 * e, b_end - 1) * g.ldgy);
+        }
 #endif
     };
     auto load_x = [&](int c, int64_t b0) {
@@ -1433,7 +1439,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const WgradSplitArgs g
         for (int e = 0; e < 2; ++e) {
             const int r = yr0 + 16 * e;
             const float sc = b0 + r < b_end ? sy : 0.f;
-            const float v0 = cy[yc][e].x * sc, v1 = cy[yc][e].y * sc, v2 = cy[yc][e].z * sc, v3 = cy[yc][e].w * sc;
+            float4 yv;
+            if (YB) {                                // bf16 = the high half of the fp32 pattern
+                const uint2 u = cyb[yc][e];
+                yv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+            } else {
+                yv = cy[yc][e];
+            }
+            const float v0 = yv.x * sc, v1 = yv.y * sc, v2 = yv.z * sc, v3 = yv.w * sc;
             bsum[0] += v0; bsum[1] += v1; bsum[2] += v2; bsum[3] += v3;
             h4 hv = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
             *reinterpret_cast<h4*>(yb + wt_off(r, ycg >> 1) + 8 * (ycg & 1)) = hv;
@@ -2461,9 +2475,14 @@ static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_
                              const void* packed_w, const int32_t* ktab, const float* bias_packed,
                              const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride,
                              uint32_t* y_max, int64_t B, int in, int out, int relu_in, int relu_out,
-                             int dtype, int k_reverse, void* stream) {
+                             int dtype, int k_reverse, void* stream, const void* x_plane = nullptr,
+                             int64_t x_plane_stride = 0) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (!linear_terms(dtype)) return NF_ERR_DTYPE;
+    // (a bf16 plane of the A operand: whole 16-wide K steps, 16-byte rows, no ReLU - NF_DTYPE_BF16 only)
+    if (x_plane && (dtype != NF_DTYPE_BF16 || relu_in || in % XS != 0 || x_plane_stride < in || x_plane_stride % 8 != 0 ||
+                    ((uintptr_t)x_plane & 15) != 0))
+        return NF_ERR_LAYOUT;
     hipStream_t s = (hipStream_t)stream;
     if (y_max) {
         hipError_t me = hipMemsetAsync(y_max, 0, sizeof(uint32_t), s);
@@ -2472,8 +2491,8 @@ static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_
     if (B == 0) return NF_OK;
     if (!x || !packed_w || !ktab || !bias_packed || !y || (dtype == NF_DTYPE_F16X2 && !x_max)) return NF_ERR_NULL;
     if (relu_out < 0 || relu_out > 2 || (relu_out == 2 && !residual)) return NF_ERR_NULL;
-    if (x_row_stride < in || y_row_stride < out || (residual && res_row_stride < out)) return NF_ERR_LAYOUT;
-    if (in % 8 != 0 || x_row_stride % 4 != 0 || ((uintptr_t)x & 15) != 0) return NF_ERR_LAYOUT;
+    if (!x_plane && (x_row_stride < in || in % 8 != 0 || x_row_stride % 4 != 0 || ((uintptr_t)x & 15) != 0)) return NF_ERR_LAYOUT;
+    if (y_row_stride < out || (residual && res_row_stride < out)) return NF_ERR_LAYOUT;
     FusedArgs g = {};
     const int nt = nf_linear_split_tiles(out);
     g.h = x; g.ldh = x_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
@@ -2487,6 +2506,13 @@ static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_
                 (!residual || (res_row_stride % 4 == 0 && ((uintptr_t)residual & 15) == 0));
     const size_t stages = (size_t)2 * 2 * linear_terms(dtype) * XA, otile = sizeof(float) * (XT / 64) * 32 * XOT;
     const size_t lds = g.vec_out && otile > stages ? otile : stages;
+    if (x_plane) {
+        g.hp = x_plane; g.hp_ld = x_plane_stride;
+        static unsigned long long pre_cap = 0;
+        if (const int rc = nf_raise_lds_cap((const void*)masked_linear_split_kernel<SplitBf16x1, false, true>, &pre_cap)) return rc;
+        hipLaunchKernelGGL((masked_linear_split_kernel<SplitBf16x1, false, true>), dim3((unsigned)grid), dim3(XT), lds, s, g);
+        return nf_launch_status();
+    }
     return dtype == NF_DTYPE_BF16X3 ? launch_linear_split<SplitBf16x3>(g, (int)grid, lds, relu_in, s)
            : dtype == NF_DTYPE_BF16 ? launch_linear_split<SplitBf16x1>(g, (int)grid, lds, relu_in, s)
                                     : launch_linear_split<SplitF16x2>(g, (int)grid, lds, relu_in, s);
@@ -2495,7 +2521,8 @@ static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_
 static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t* x_max, const float* grad_y,
                             int64_t grad_y_row_stride, const uint32_t* grad_y_max, const float* mask,
                             const int32_t* ktab, float* grad_w, float* grad_b, int64_t B, int in, int out, int relu_in,
-                            int terms, void* stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
+                            int terms, void* stream, void* workspace = nullptr, size_t workspace_bytes = 0,
+                            bool gy_bf16 = false) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (B == 0) return NF_OK;
     if (!x || !grad_y || !grad_w || !x_max || !grad_y_max) return NF_ERR_NULL;
@@ -2534,6 +2561,7 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
     const bool planes_ok = workspace && (terms == 2 || (int64_t)((out + WT_N - 1) / WT_N) * ((in + 255) / 256) > 128) && in % 8 == 0 &&
                            ((uintptr_t)workspace & 15) == 0 &&
                            workspace_bytes >= (size_t)terms * (size_t)B * in * sizeof(_Float16);
+    if (gy_bf16 && !(tr_ok && planes_ok && terms == 1 && ((uintptr_t)grad_y & 7) == 0)) return NF_ERR_LAYOUT;
     if (tr_ok && (terms == 1 || planes_ok)) {
         g.nt = (out + WT_N - 1) / WT_N;
         // a wide layer with a caller's workspace: x goes through its fp16 plane (every workgroup of a batch split
@@ -2572,6 +2600,12 @@ static int wgrad_split_impl(const float* x, int64_t x_row_stride, const uint32_t
             }
             hipLaunchKernelGGL(half_plane_kernel<1>, pg, dim3(256), 0, s, x, x_row_stride, B, in, g.x_max, relu_in,
                                (_Float16*)workspace);
+            if (gy_bf16) {
+                static unsigned long long yb_cap = 0;
+                if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<true, 256, 1, true>, &yb_cap)) return e;
+                hipLaunchKernelGGL((wgrad_tr_kernel<true, 256, 1, true>), dim3((unsigned)bk), dim3(512), (2 + 3 * 2) * WT_IMG, s, g);
+                return nf_launch_status();
+            }
             if (const int e = nf_raise_lds_cap((const void*)wgrad_tr_kernel<true, 256>, &tr_cap[1])) return e;
             hipLaunchKernelGGL((wgrad_tr_kernel<true, 256>), dim3((unsigned)bk), dim3(512), (2 + 3 * 2) * WT_IMG, s, g);
             return nf_launch_status();
@@ -2616,6 +2650,30 @@ extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_s
                                                  void* stream) {
     return wgrad_split_impl(x, x_row_stride, x_max, grad_y, grad_y_row_stride, grad_y_max, mask, ktab, grad_w, grad_b, B,
                             in, out, relu_in, 2, stream);
+}
+
+// nf_masked_linear_split_bwd_input (NF_DTYPE_BF16) with grad_y given as a bf16 matrix (nf_rqs_bwd_max_bf16's output):
+// the A operand goes from memory to LDS as it is - half the bytes, no conversion.  out % 16 == 0, 16-byte rows.
+extern "C" int nf_masked_linear_split_bwd_input_bf16(const void* grad_y_bf16, int64_t grad_y_row_stride,
+                                                     const void* packed_wt, const int32_t* ktab_t, const float* bias_zero,
+                                                     const float* gate, int64_t gate_row_stride, float* grad_x,
+                                                     int64_t grad_x_row_stride, uint32_t* grad_x_max, int64_t B, int out,
+                                                     int in, void* stream) {
+    if (!grad_y_bf16) return NF_ERR_NULL;
+    return linear_split_impl((const float*)grad_y_bf16, grad_y_row_stride, nullptr, packed_wt, ktab_t, bias_zero, gate,
+                             gate_row_stride, grad_x, grad_x_row_stride, grad_x_max, B, out, in, 0, gate ? 2 : 0,
+                             NF_DTYPE_BF16, 1, stream, grad_y_bf16, grad_y_row_stride);
+}
+
+// nf_masked_linear_half_bwd_weight with grad_y given as a bf16 matrix (nf_rqs_bwd_max_bf16's output; row stride in
+// elements, 8-byte aligned rows): wide layers only (the workspace path), else NF_ERR_LAYOUT.
+extern "C" int nf_masked_linear_half_bwd_weight_bf16(const float* x, int64_t x_row_stride, const uint32_t* x_max,
+                                                     const void* grad_y_bf16, int64_t grad_y_row_stride,
+                                                     const uint32_t* grad_y_max, const float* mask, const int32_t* ktab,
+                                                     float* grad_w, float* grad_b, int64_t B, int in, int out,
+                                                     int relu_in, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_split_impl(x, x_row_stride, x_max, (const float*)grad_y_bf16, grad_y_row_stride, grad_y_max, mask, ktab,
+                            grad_w, grad_b, B, in, out, relu_in, 1, stream, workspace, workspace_bytes, true);
 }
 
 // The same with a caller-owned workspace (2 * B * in * 2 bytes, 16-byte aligned): the transposed-read kernel with act(x)

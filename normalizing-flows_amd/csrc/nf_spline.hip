@@ -235,6 +235,8 @@ struct RqsBwdArgs {
     int vec_ok;                // params AND gparams 16-byte aligned
     int inverse;               // backward of the inverse direction (x = the inverse pass's OUTPUT, see rqs_bwd_eval)
     unsigned* gmax;            // nullable: atomicMax of the bit pattern of the largest finite |grad_params| written
+    __bf16* gparams16;         // nullable: grad_params go HERE as bf16 [B, D*P] instead of to gparams (the bf16 training
+                               // mode's backward GEMMs round them to 8 bits anyway: half the bytes written and re-read)
 };
 
 // FAM 0: rational-quadratic (gradients overwrite the staged parameters in place); 1 / 2 / 3: linear / quadratic /
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     const bool flat = a.x_stride == D && a.gy_stride == D && a.gx_stride == D;
     const float inv_d = 1.0f / (float)D;
     float* gbase = a.gparams + (gblk - st.shift);          // 16-byte aligned when st.vec
+    __bf16* gbase16 = a.gparams16 ? a.gparams16 + (gblk - st.shift) : nullptr;     // (then 8-byte aligned)
 
     auto locate = [&](int e, int64_t& xi, int64_t& gyi, int64_t& gxi, int& r) {
         r = div_small(e, D, inv_d);
@@ -319,6 +322,8 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
         const int lo = st.shift, hi = st.shift + n * P;
         const int nvec = (hi + 3) >> 2;
         float* gspan = gbase + (int64_t)it0 * P;
+        __bf16* gspan16 = gbase16 + (int64_t)it0 * P;
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int v = tid + i * kThreads;
@@ -326,12 +331,21 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
             const int f = 4 * v;
             if (st.vec && f >= lo && f + 3 < hi) {
                 const float4 gv = *reinterpret_cast<const float4*>(gout + f);
-                *reinterpret_cast<float4*>(gspan + f) = gv;
+                if (gbase16) {
+                    const bf16x4_t hv = {(__bf16)gv.x, (__bf16)gv.y, (__bf16)gv.z, (__bf16)gv.w};
+                    *reinterpret_cast<bf16x4_t*>(gspan16 + f) = hv;
+                } else {
+                    *reinterpret_cast<float4*>(gspan + f) = gv;
+                }
                 seen(gv.x); seen(gv.y); seen(gv.z); seen(gv.w);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (f + q >= lo && f + q < hi) { gspan[f + q] = gout[f + q]; seen(gout[f + q]); }
+                    if (f + q >= lo && f + q < hi) {
+                        if (gbase16) gspan16[f + q] = (__bf16)gout[f + q];
+                        else gspan[f + q] = gout[f + q];
+                        seen(gout[f + q]);
+                    }
             }
         }
     }
@@ -767,7 +781,8 @@ static int rqs_bwd_impl(const float* x, int64_t x_row_stride, const float* param
                         double pre_div, const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
                         float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D, int K,
                         int tails, double tail_bound, double min_bin_width, double min_bin_height,
-                        double min_derivative, int inverse, void* stream, uint32_t* grad_params_max = nullptr) {
+                        double min_derivative, int inverse, void* stream, uint32_t* grad_params_max = nullptr,
+                        void* grad_params_bf16 = nullptr) {
     if (B < 0 || D <= 0 || K <= 0 || K > 32) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
     if (grad_params_max) {                                 // the slot starts at 0 even for an empty batch
@@ -775,7 +790,7 @@ static int rqs_bwd_impl(const float* x, int64_t x_row_stride, const float* param
         if (me != hipSuccess) return (int)me;
     }
     if (B == 0) return NF_OK;
-    if (!x || !params || !grad_y || !grad_logabsdet || !grad_x || !grad_params) return NF_ERR_NULL;
+    if (!x || !params || !grad_y || !grad_logabsdet || !grad_x || (!grad_params && !grad_params_bf16)) return NF_ERR_NULL;
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
     if (param_row_stride != (int64_t)D * P) return NF_ERR_LAYOUT;
     if (x_row_stride < D || grad_y_row_stride < D || grad_x_row_stride < D) return NF_ERR_LAYOUT;
@@ -785,9 +800,10 @@ static int rqs_bwd_impl(const float* x, int64_t x_row_stride, const float* param
     a.gx_stride = grad_x_row_stride; a.gparams = grad_params; a.B = B; a.D = D;
     a.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, pre_div);
     a.rows_per_block = pick_rows_per_block(D, B);
-    a.vec_ok = (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0;
+    a.vec_ok = (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0 && ((uintptr_t)grad_params_bf16 & 7) == 0;
     a.inverse = inverse;
     a.gmax = grad_params_max;
+    a.gparams16 = (__bf16*)grad_params_bf16;
     const size_t lds = sizeof(float) * (size_t)((kThreads * P + 4 + 3) & ~3);
     const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
@@ -837,6 +853,7 @@ static int family_bwd(const float* x, int64_t x_row_stride, const float* params,
     a.vec_ok = (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0;
     a.inverse = inverse;
     a.gmax = nullptr;
+    a.gparams16 = nullptr;
     const size_t lds = 2 * sizeof(float) * (size_t)((kThreads * P + 4 + 3) & ~3);     // parameters + gradients
     if (lds > 160 * 1024) return NF_ERR_SHAPE;
     const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
@@ -890,6 +907,22 @@ extern "C" int nf_rqs_bwd_max(const float* x, int64_t x_row_stride, const float*
     return rqs_bwd_impl(x, x_row_stride, params, param_row_stride, pre_div, grad_y, grad_y_row_stride, grad_logabsdet,
                         grad_x, grad_x_row_stride, grad_params, B, D, K, tails, tail_bound, min_bin_width,
                         min_bin_height, min_derivative, inverse ? 1 : 0, stream, grad_params_max);
+}
+
+// nf_rqs_bwd_max with grad_params written as bf16 [B, D*P] (8-byte aligned): for a caller whose next step rounds them
+// to bf16 anyway - the bf16 training mode, where the two backward GEMMs of the final layer are their only readers.
+// The slot still receives the largest |gradient| before rounding.
+extern "C" int nf_rqs_bwd_max_bf16(const float* x, int64_t x_row_stride, const float* params, int64_t param_row_stride,
+                                   double pre_div, const float* grad_y, int64_t grad_y_row_stride,
+                                   const float* grad_logabsdet, float* grad_x, int64_t grad_x_row_stride,
+                                   void* grad_params_bf16, uint32_t* grad_params_max, int64_t B, int D, int K, int tails,
+                                   double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                                   int inverse, void* stream) {
+    if (!grad_params_max || !grad_params_bf16) return NF_ERR_NULL;
+    if (((uintptr_t)grad_params_bf16 & 7) != 0) return NF_ERR_LAYOUT;
+    return rqs_bwd_impl(x, x_row_stride, params, param_row_stride, pre_div, grad_y, grad_y_row_stride, grad_logabsdet,
+                        grad_x, grad_x_row_stride, nullptr, B, D, K, tails, tail_bound, min_bin_width, min_bin_height,
+                        min_derivative, inverse ? 1 : 0, stream, grad_params_max, grad_params_bf16);
 }
 
 // Backward of nf_rqs_fwd(inverse = 1): x_out = the inverse pass's OUTPUT, grad_x_out / grad_logabsdet the gradients
