@@ -11,6 +11,11 @@ model.py:233-244).  Here every forward kernel has a hand-written backward kernel
                    implicitly at its output (nf_rqs_inverse_bwd)
   AffineFn       : (y, logabsdet) = sigmoid-scale affine(x; params), either direction, AR or coupling layout
                    backward: recompute-from-inputs kernel nf_rqs_bwd -> grad_x, grad_params
+  FinalRqsFn     : final MADE layer + RQ spline of a whole autoregressive layer as ONE node (f32 / bf16 modes): forward
+                   nf_made_rqs_fwd_params (the parameters kept, not re-read between GEMM and spline); backward
+                   nf_rqs_bwd_max + the final layer's two GEMMs - in bf16 mode with the parameter gradients as a bf16
+                   plane between the three kernels (nf_rqs_bwd_max_bf16, nf_masked_linear_split_bwd_input_bf16,
+                   nf_masked_linear_half_bwd_weight_bf16)
 """
 import torch
 
