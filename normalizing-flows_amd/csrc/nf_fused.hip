@@ -352,17 +352,19 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] *= uf;
         }
+        const bool whole = m0 + FM <= g.M;           // (uniform) every row of the tile exists: no per-store test
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = wc * 64 + j * 32 + (lane & 31);
             if (col >= fv * P) continue;
-            float* pc = g.params_out + (int64_t)f0 * P + col;
+            // this lane's rows are m0 + 4 (lane >> 5) + {0..3} + 8 {0..3} + 32 i: one base pointer, constant row offsets
+            float* pc = g.params_out + (int64_t)f0 * P + col + (m0 + 4 * (lane >> 5)) * g.ldp;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + i * HR + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < g.M) pc[row * g.ldp] = acc[i][j][r];
+                    const int k = i * HR + (r & 3) + 8 * (r >> 2);
+                    if (whole || m0 + k + 4 * (lane >> 5) < g.M) pc[k * g.ldp] = acc[i][j][r];
                 }
         }
     }
