@@ -150,6 +150,114 @@ def two_moons_leg(nf, dev, steps):
             'parity_max_rel_err_vs_oracle': err, 'mean_log_prob': lp.double().mean().item()}
 
 
+def launch_ranks(n, argv, script=None, stdout=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU,
+    rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  Called BEFORE this process has made any GPU call -
+    the parent only waits - so nothing that has initialised the GPU is ever replaced or re-executed.
+    Returns the children's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, min(16, (os.cpu_count() or 8) // max(1, n)))))
+    return subprocess.run(cmd, env=env, stdout=stdout).returncode
+
+
+def worker_stub(args):
+    """--worker-stub: what a rank does around the timed region (process group, barrier, MAX over ranks, one line from
+    rank 0) with no GPU work in between - tests/test_bench_launch.py drives `--gpus 2` through it on gloo."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+        dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    seen = torch.ones(1, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({'metric': 'stub', 'n_gpus': world, 'ranks_seen': int(seen.item()), 'gpus_flag': args.gpus,
+                          'steps': args.steps, 'warmup': args.warmup, 'max_over_ranks': t.item()}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def coupling_cfg2_leg(nf, dev, steps, cpu_sample):
+    """BASELINE.json configs[1]: 8 x PiecewiseRationalQuadraticCouplingTransform, D = 64, alternating masks,
+    ResidualNet(hidden 32, 2 blocks) conditioners, K = 8, linear tails +-3, B = 1048576, log_prob in the library's
+    default (exact fp32) matrix mode.  Reference path: transforms.py:80-106, :212-247, nn/resnet.py:90-100.
+    HBM accounting per SURVEY 8(d): 3460 algorithmic bytes per sample per layer; spline elements = B x 32 per layer."""
+    from oracle import nf_oracle as O
+    Dc, HID, Kc, Lc, Bc = 64, 32, 8, 8, 1 << 20
+    torch.manual_seed(0)
+    layers = []
+    for i in range(Lc):
+        mask = torch.ones(Dc)
+        mask[i % 2::2] = -1        # alternating binary mask (reference helper_functions.py:461-472)
+        layers.append(nf.PiecewiseRationalQuadraticCouplingTransform(
+            mask, lambda i_, o_: nf.ResidualNet(i_, o_, hidden_features=HID, num_blocks=2),
+            num_bins=Kc, tails='linear', tail_bound=T))
+    flow = nf.BaseNeuralSplineFlow(nf.CompositeTransform(layers), nf.StandardNormal([Dc]))
+    sd = {k: v.clone() for k, v in flow.state_dict().items()}
+    flow = flow.to(dev).eval()
+    x = torch.randn(Bc, Dc, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
+    prev = nf.get_matmul_dtype()
+    nf.set_matmul_dtype('f32')
+    try:
+        with torch.no_grad():
+            lp = flow.log_prob(x)
+            tm = nf._lib.KernelTimer()
+            nf._lib.set_timer(tm)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                lp = flow.log_prob(x)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            nf._lib.set_timer(None)
+    finally:
+        nf._lib.set_timer(None)
+        nf.set_matmul_dtype(prev)
+    kern = tm.summary()
+    byts = Lc * 3460
+    out = {'workload': 'cfg2: 8x RQ-spline coupling layer D=64 K=8 ResidualNet(32, 2 blocks) tails=linear T=3, log_prob',
+           'value': Bc / dt, 'unit': 'samples/s (this rank)', 'batch': Bc, 'ms_per_step': 1e3 * dt, 'dtype': 'f32',
+           'roofline': {'bound': 'hbm', 'achieved': Bc * byts / dt / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': Bc * byts / dt / 1e9 / PEAK_HBM_GBS, 'algorithmic_bytes_per_sample': byts,
+                        'note': 'whole step (all launches of the 8 layers) against SURVEY 8(d)\'s 3460 B per sample '
+                                'and layer'},
+           'kernel_ms': {'%s_%dx%d_rows%d' % (k[0], k[1], k[2], k[3]): round(v[1], 4) for k, v in kern.items()}}
+    fused = [k for k in kern if k[0] == 'made_rqs']
+    if fused:
+        out['spline_elements_per_s_in_fused_kernel'] = fused[0][3] * (Dc // 2) / (kern[fused[0]][1] * 1e-3)
+    if cpu_sample:
+        n = min(cpu_sample, Bc)
+        xc = x[:n].cpu()
+        tsd = {k[len('_transform.'):]: v for k, v in sd.items() if k.startswith('_transform.')}
+        funcs = []
+        for j in range(Lc):
+            s_ = O.split_state_dict(tsd, j)
+            funcs.append(lambda v, s_=s_: O.rq_coupling(s_, v, Kc, 'linear', T, hidden_features=HID))
+        best = float('inf')
+        with torch.no_grad():
+            for _ in range(2):
+                t1 = time.perf_counter()
+                ref = O.flow_log_prob(funcs, xc)
+                best = min(best, time.perf_counter() - t1)
+        out['parity_max_rel_err_vs_oracle'] = ((lp[:n].cpu().double() - ref.double()).abs()
+                                               / ref.double().abs().clamp_min(1.0)).max().item()
+        out['cpu_baseline'] = {'value': n / best, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                               'sample': 'oracle on the first %d samples, best of 2' % n}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -164,17 +272,30 @@ def main():
                          'groups of --batch rows (nothing of size [total, D] is ever resident)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-bf16', action='store_true', help='skip the secondary measurements in the other modes')
+    ap.add_argument('--worker-stub', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # no launcher around us: become one (fresh child processes; this parent never touches the GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or run `python bench.py '
+                 '--gpus %d` without a launcher, which starts the ranks itself)' % (args.gpus, world, args.gpus, args.gpus))
+    if args.worker_stub:
+        return worker_stub(args)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        ranks_seen = dist.get_world_size()
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -242,7 +363,7 @@ def main():
         total = world * per_step * args.steps
         out = {
             'metric': 'log_prob samples/sec (fwd+logdet), RQ-spline MAF D=784',
-            'value': total / elapsed, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
+            'value': total / elapsed, 'unit': 'samples/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': DTYPE_LABEL[args.dtype],
@@ -300,15 +421,36 @@ def main():
             zs = torch.randn(ns, D, device=dev, generator=torch.Generator(device=dev).manual_seed(99))
             with torch.no_grad():
                 xs, lds = flow.forward(zs)
+                ti = nf._lib.KernelTimer()
+                nf._lib.set_timer(ti)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 xs, lds = flow.forward(zs)
                 torch.cuda.synchronize()
                 dts = time.perf_counter() - t1
+                nf._lib.set_timer(None)
                 zb, ldb = flow.reverse(xs)
             out['inverse_sampling'] = {'value': ns / dts, 'unit': 'samples/s (this rank)', 'batch': ns,
                                        'roundtrip_max_abs_err': (zb - zs).abs().max().item(),
                                        'logdet_cancel_max_abs': (lds + ldb).abs().max().item()}
+            ki = ti.summary()
+            rows_k = [k for k in ki if k[0] == 'made_rqs_inverse_rows']
+            if rows_k:
+                # the row-resident kernel does one conditioner pass of work per sample (13.74 MFLOP unmasked MACs x 2,
+                # SURVEY 8d) on fp32 MFMA; its launch time from HIP events on the launch stream
+                made = flow._transform._transforms[0].autoregressive_net
+                nnz_all = float(sum(l.mask.sum().item() for l in made.modules() if hasattr(l, 'mask')))
+                n_l, ms_l = ki[rows_k[0]]
+                ach = 2.0 * nnz_all * rows_k[0][3] / (ms_l * 1e-3) / 1e12
+                out['inverse_sampling']['roofline'] = {
+                    'bound': 'mfma', 'kernel': 'made_rqs_inverse_kernel (features 0..H of one layer, row-resident)',
+                    'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                    'launches': n_l, 'avg_launch_ms': ms_l, 'rows_per_launch': rows_k[0][3],
+                    'algorithmic_flop_per_launch': 2.0 * nnz_all * rows_k[0][3], 'traffic': None}
+                out['inverse_sampling']['kernel_ms'] = {'%s_%dx%d_rows%d' % (k[0], k[1], k[2], k[3]): round(v[1], 4)
+                                                        for k, v in ki.items()}
+            # BASELINE.json configs[1] in the same driver-timed line
+            out['coupling_cfg2'] = coupling_cfg2_leg(nf, dev, max(args.steps // 2, 3), 0 if args.no_cpu else 65536)
         f32_tf, bf16_tf, copy_gbs, f16_rand_tf = nf._lib.measure_device_peaks()
         out['measured_device_peaks'] = {'mfma_f32_tflops': f32_tf, 'mfma_bf16_tflops': bf16_tf, 'copy_gbs': copy_gbs,
                                         'mfma_f16_random_operand_tflops': f16_rand_tf,
@@ -319,8 +461,8 @@ def main():
                                                 'roofline fractions above use the nominal peaks'}
         if 'roofline' in out and args.dtype != 'f32' and f16_rand_tf > 0:
             out['roofline']['executed_frac_of_measured_random_operand_peak'] = out['roofline']['executed_tflops'] / f16_rand_tf
-        if world == 1 and not args.stream_total:
-            out['two_moons'] = two_moons_leg(nf, dev, max(args.steps, 3))
+        if not args.stream_total:
+            out['two_moons'] = two_moons_leg(nf, dev, max(args.steps, 3))     # (rank 0's GPU, after the timed region)
         if not args.no_cpu and world == 1:
             n = min(args.cpu_sample, B)
             v, cores, err = cpu_baseline(sd_cpu, x[:n].cpu(), logp[:n].cpu(), reps=3)
@@ -329,6 +471,9 @@ def main():
                                    'sample': 'oracle (reference ATen op sequence, fp32, torch CPU) on the first %d '
                                              'samples of rank 0, best of 3' % n}
             out['parity_max_rel_err_vs_oracle'] = err
+        elif world > 1:
+            out['cpu_baseline_note'] = ('the oracle is timed on rank 0 of the N=1 run only (the N=1 line carries '
+                                        'cpu_baseline and the parity figure); secondary legs likewise')
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

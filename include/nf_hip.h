@@ -221,7 +221,12 @@ int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h
  * hipFree / allocating routine; the first call on a device resolves that device's copy of the array (make it outside
  * graph capture; B = 0 does that and launches nothing).  Every call on a GPU shares that GPU's array: calls that
  * overlap on one GPU (different streams or threads) race - serialise them.  Nothing in the array needs to start at
- * zero (every value read is written first by the same call).  Results are those of nf_made_rqs_fwd, bit for bit. */
+ * zero (every value read is written first by the same call).  Results are those of nf_made_rqs_fwd called with an
+ * 8 MiB workspace, bit for bit: for NF_DTYPE_F32 / NF_DTYPE_BF16 that is nf_made_rqs_fwd's result with any workspace;
+ * for NF_DTYPE_F16X2 / BF16X3 the kernel is chosen from the workspace size - when the hidden state's pre-split term
+ * planes (terms * B * kpad(in) * 2 bytes beside the partials; in = 512: B <= ~3900) fit the array the plane kernel
+ * runs, past that the kernel that splits the hidden state inside its K loop (slower, another accumulation order:
+ * equal to the plane kernel's results within the 1e-5 contract, not bit for bit). */
 int nf_made_rqs_fwd_noalloc(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
                             const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
                             int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx, int64_t B, int in,

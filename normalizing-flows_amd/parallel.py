@@ -176,6 +176,10 @@ class GradientSynchronizer:
             sync.finish()                     # gradients are now the mean over ranks
             optimizer.step()
 
+    One backward() per zero_grad() / finish() pair: a gradient that arrives for a bucket whose all-reduce is already
+    under way raises (it would race with the collective); accumulate with `with sync.no_sync(): loss.backward()` for
+    all but the last micro-batch.
+
     The reference has no counterpart (single process).  With world size 1 (or no process group) it only provides
     the flat views and `finish()` is a no-op."""
 
@@ -194,7 +198,22 @@ class GradientSynchronizer:
                 cur, size = [], 0
         if cur:
             self._make_bucket(cur)
+        self._defer = False
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward passes inside it only add into the flat buffers; the
+        buckets are reduced by the next backward outside it (hooks) or by finish()."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev, self._defer = self._defer, True
+            try:
+                yield self
+            finally:
+                self._defer = prev
+        return cm()
 
     def _make_bucket(self, params):
         dtype, device = params[0].dtype, params[0].device
@@ -225,6 +244,14 @@ class GradientSynchronizer:
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
             p.grad = v
+        if b['pending'] <= 0 or b['work'] is not None:
+            # a second backward() before finish(): the bucket's all-reduce may still be reading the flat buffer this
+            # gradient was just accumulated into, and the count can no longer tell when the bucket is complete
+            raise RuntimeError('GradientSynchronizer: a gradient arrived for a bucket that is already complete - '
+                               'call finish() (and zero_grad()) between backward passes; to accumulate gradients over '
+                               'several backward passes wrap all but the last in `with sync.no_sync():`')
+        if self._defer:
+            return
         b['pending'] -= 1
         if b['pending'] == 0 and self.world > 1:
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -253,24 +280,45 @@ class GradientSynchronizer:
 
 
 class _SyncBatchNormFn(torch.autograd.Function):
-    """Training-mode batch normalisation over the GLOBAL batch: statistics from one all-reduce(SUM) of
-    [sum x, sum x^2, n] per feature, backward from one all-reduce(SUM) of [sum dy, sum dy*xhat]."""
+    """Training-mode batch normalisation over the GLOBAL batch.  Forward: every rank computes [n, mean, M2 = sum
+    (x - mean)^2] of its shard (the centred form nn.BatchNorm1d itself uses: no cancellation when |mean| >> std), ONE
+    all-gather of those 2F+1 float64 values, and the pairwise (Chan et al.) combination on every rank in float64 and in
+    rank order - so all ranks hold bit-identical statistics.  Backward: one all-reduce(SUM) of [sum dy, sum dy*xhat].
+    weight / bias may be None (affine=False)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps, group):
-        n_local = x.shape[0]
-        stats = torch.cat([x.sum(0), (x * x).sum(0), x.new_full((1,), float(n_local))])
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         F_ = x.shape[1]
-        n = stats[-1]
-        mean = stats[:F_] / n
-        var = (stats[F_:2 * F_] / n - mean * mean).clamp_min(0.0)          # biased, as F.batch_norm normalises with
-        invstd = torch.rsqrt(var + eps)
+        n_local = x.shape[0]
+        x64 = x.double()
+        if n_local:
+            mean_l = x64.mean(0)
+            m2_l = ((x64 - mean_l) ** 2).sum(0)
+        else:                                   # an empty shard still takes part in the collective
+            mean_l = x64.new_zeros(F_)
+            m2_l = x64.new_zeros(F_)
+        part = torch.cat([x64.new_full((1,), float(n_local)), mean_l, m2_l])
+        world = dist.get_world_size(group)
+        parts = [torch.empty_like(part) for _ in range(world)]
+        dist.all_gather(parts, part, group=group)
+        allp = torch.stack(parts)                                   # [world, 2F+1]
+        ns = allp[:, :1]
+        n = ns.sum()
+        mean64 = (ns * allp[:, 1:1 + F_]).sum(0) / n
+        m2 = (allp[:, 1 + F_:] + ns * (allp[:, 1:1 + F_] - mean64) ** 2).sum(0)
+        var64 = m2 / n                                              # biased, as F.batch_norm normalises with
+        invstd = torch.rsqrt(var64 + eps).to(x.dtype)
+        mean = mean64.to(x.dtype)
         xhat = (x - mean) * invstd
         ctx.save_for_backward(xhat, weight, invstd)
-        ctx.group, ctx.n = group, n
-        ctx.mark_non_differentiable(mean, var, n)
-        return xhat * weight + bias, mean, var, n
+        ctx.group, ctx.n, ctx.has_bias = group, n.to(x.dtype), bias is not None
+        var = var64.to(x.dtype)
+        n_out = n.to(x.dtype)
+        ctx.mark_non_differentiable(mean, var, n_out)
+        y = xhat if weight is None else xhat * weight
+        if bias is not None:
+            y = y + bias
+        return y, mean, var, n_out
 
     @staticmethod
     def backward(ctx, gy, _gm, _gv, _gn):
@@ -280,8 +328,8 @@ class _SyncBatchNormFn(torch.autograd.Function):
         gb_local, gw_local = sums[:F_].clone(), sums[F_:].clone()         # parameter gradients stay LOCAL sums: the
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)      # gradient all-reduce adds them up like any other
         n = ctx.n
-        gx = (gy - sums[:F_] / n - xhat * (sums[F_:] / n)) * (weight * invstd)
-        return gx, gw_local, gb_local, None, None
+        gx = (gy - sums[:F_] / n - xhat * (sums[F_:] / n)) * (invstd if weight is None else weight * invstd)
+        return gx, (None if weight is None else gw_local), (gb_local if ctx.has_bias else None), None, None
 
 
 class SyncBatchNorm1d(nn.BatchNorm1d):

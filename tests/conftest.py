@@ -41,3 +41,13 @@ def rel_err(a, b, floor=1.0):
 @pytest.fixture(scope='session')
 def has_gpu():
     return torch.cuda.is_available()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Measured gradient distances (tests/test_gpu_parity.py::assert_grad_close): the worst ratio to the bar."""
+    mod = sys.modules.get('test_gpu_parity')
+    rep = getattr(mod, 'GRAD_REPORT', None)
+    if rep:
+        worst = sorted(rep, key=lambda r: -r[1])[:5]
+        terminalreporter.write_line('gradient parity (name, err / max|ref|, oracle fp32 floor): ' +
+                                    '; '.join('%s %.2e %.2e' % r for r in worst))

@@ -54,6 +54,23 @@ def assert_close(got, ref64, ref32=None, tol=TOL, mult=4.0):
         assert q <= max(tol, 2 * qref), (q, qref)
 
 
+GRAD_TOL = 2e-5
+GRAD_REPORT = []
+
+
+def assert_grad_close(name, got, ref64, ref32, tight=GRAD_TOL, mult=4.0):
+    """Gradients: max|got - ref64| / max|ref64| <= max(tight, mult x the same distance of the ORACLE's own fp32
+    autograd from its fp64 autograd) - the rule assert_close applies to values (ADVICE / VERDICT round 2: a flat
+    2e-3 was not tied to any measured floor).  `tight` is what well-conditioned tensors meet."""
+    got = torch.as_tensor(got).double().cpu()
+    ref64 = torch.as_tensor(ref64).double()
+    scale = ref64.abs().max().item() + 1e-300
+    err = (got - ref64).abs().max().item() / scale
+    floor = (torch.as_tensor(ref32).double() - ref64).abs().max().item() / scale
+    GRAD_REPORT.append((name, err, floor))
+    assert err <= max(tight, mult * floor), (name, err, floor)
+
+
 def check_bins(bins_hip, bins_ref, x, knots, tol):
     """Bit-exact, except where x sits within `tol` of the knot separating the two answers (there the
     reference's own fp32 and fp64 runs may disagree too).  Returns the number of such flips."""
@@ -245,12 +262,19 @@ def test_activations_other_than_relu_golden(nf, act):
     x64 = x.double().requires_grad_(True)
     wy, wl = O.rq_autoregressive_forward(full, x64, K, 3.0, activation=ACTS[act])
     (wy.square().sum() * 0.5 - wl.sum()).backward()
-    assert rel_err(xg.grad.cpu(), x64.grad) < 2e-3
+    # the floor: the oracle's own fp32 autograd for the same loss
+    leaves32 = {k: v.detach().float().requires_grad_(True) for k, v in leaves.items()}
+    full32 = dict(sd)
+    full32.update(leaves32)
+    x32 = x.clone().requires_grad_(True)
+    fy, fl = O.rq_autoregressive_forward(full32, x32, K, 3.0, activation=ACTS[act])
+    (fy.square().sum() * 0.5 - fl.sum()).backward()
+    assert_grad_close('inputs', xg.grad, x64.grad, x32.grad)
     named = dict(t.named_parameters())
     checked = 0
     for k, v in leaves.items():
         if k in named and v.grad is not None:
-            assert rel_err(named[k].grad.cpu(), v.grad) < 2e-3, k        # the suite's fp32-vs-fp64 gradient bar
+            assert_grad_close(k, named[k].grad, v.grad, leaves32[k].grad)
             checked += 1
     assert checked >= 6
 
@@ -1253,20 +1277,22 @@ def test_training_gradients_match_autograd_of_the_oracle(nf, D, H, K, B):
     want = _oracle_loss(sd64, x64, K, Tb)
     want.backward()
     assert abs(loss.item() - want.item()) < 2e-5 * abs(want.item())
-    gxe = (xg.grad.cpu().double() - x64.grad).abs().max().item() / x64.grad.abs().max().item()
-    assert gxe < 2e-3, gxe
+    # the floor: the oracle's own fp32 autograd
+    sd32 = [{k: (v.clone().requires_grad_(True) if k.endswith(('weight', 'bias')) else v) for k, v in sd.items()}
+            for sd in sds]
+    x32 = x.clone().requires_grad_(True)
+    _oracle_loss(sd32, x32, K, Tb).backward()
+    assert_grad_close('inputs', xg.grad, x64.grad, x32.grad)
     named = dict(flow.named_parameters())
     for j in range(L):
         for k, v in sd64[j].items():
             if not k.endswith(('weight', 'bias')):
                 continue
             got = named['_transform._transforms.%d.%s' % (j, k)].grad.cpu().double()
-            ref = v.grad
             if k.endswith('weight'):        # masked entries: the oracle's W*mask gives them exactly zero gradient
                 mask = sd64[j][k[:-len('weight')] + 'mask']
                 assert (got[mask == 0] == 0).all(), k
-            scale = ref.abs().max().item() + 1e-12
-            assert ((got - ref).abs().max().item() / scale) < 2e-3, (k, (got - ref).abs().max().item(), scale)
+            assert_grad_close('%d.%s' % (j, k), got, v.grad, sd32[j][k].grad)
 
 
 @pytest.mark.parametrize('mode,B,D,H,K', [('f32', 130, 40, 136, 4), ('f32', 64, 23, 64, 8), ('bf16', 200, 50, 128, 8),
@@ -2455,3 +2481,55 @@ def test_half_precision_weight_gradient_transposed_read_kernel(nf, shape):
     xs.copy_(x)
     gw2, gb2 = nf._lib.masked_linear_split_bwd_weight(xs, gy, mask, None, relu, want_bias=True, terms=1)
     assert _nerr(gw, gw2.double()) < 1e-5 and _nerr(gb, gb2.double()) < 1e-5
+
+
+# ------------------------------------------------------------------ data-parallel glue on the HIP autograd path
+@pytest.mark.parametrize('mode', ['f32', 'bf16', 'f16x2'])
+def test_gradient_synchronizer_through_the_hip_autograd_functions(nf, mode):
+    """parallel.GradientSynchronizer at world size 1 around a training step of a small RQ-spline MAF whose backward
+    runs through MaskedLinearFn / FinalRqsFn / RqsFn (fresh gradient tensors accumulated into the flat bucket views):
+    zero_grad -> backward -> finish gives the gradients of the plain step, `.grad` is still the flat view afterwards,
+    a second step re-uses the views, and Adam steps on them move the weights like the plain optimizer's."""
+    from normalizing_flows_amd import parallel
+    D, H, K, B, Tb = 24, 64, 8, 256, 3.0
+    sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=90 + j, scale=0.1) for j in range(2)]
+    x = (torch.randn(B, D, generator=torch.Generator().manual_seed(8)) * 1.2).cuda()
+    nf.set_matmul_dtype(mode)
+    try:
+        def make():
+            return nf.BaseNeuralSplineFlow(nf.CompositeTransform(_load_layers(nf, sds, D, H, K, Tb)),
+                                           nf.StandardNormal([D])).cuda().train()
+        plain, synced = make(), make()
+        opt_p = torch.optim.Adam(plain.parameters(), lr=1e-3)
+        opt_s = torch.optim.Adam(synced.parameters(), lr=1e-3)
+        sync = parallel.GradientSynchronizer(synced.parameters(), bucket_bytes=64 << 10)
+        assert len(sync.buckets) >= 2
+        for step in range(2):
+            opt_p.zero_grad(set_to_none=True)
+            (-plain.log_prob(x).mean()).backward()
+            sync.zero_grad()
+            (-synced.log_prob(x).mean()).backward()
+            assert sync.finish() == 0                       # (no collective at world size 1)
+            for (k, p), q in zip(plain.named_parameters(), synced.parameters()):
+                b, v = sync._bucket_of[q]
+                assert q.grad is v and q.grad.data_ptr() == v.data_ptr(), k       # still the flat view
+                scale = p.grad.abs().max().item() + 1e-20
+                # same kernels on the same inputs; the weight gradients' fp32 atomics may land in another order
+                assert (q.grad - p.grad).abs().max().item() <= 2e-5 * scale, (mode, step, k)
+            flat = torch.cat([b['flat'] for b in sync.buckets])
+            assert flat.numel() == sum(p.numel() for p in synced.parameters()) and flat.abs().sum().item() > 0
+            opt_p.step()
+            opt_s.step()
+        moved = 0
+        for (k, p), q in zip(plain.named_parameters(), synced.parameters()):
+            # Adam divides by |g|: entries whose gradient is rounding noise may step either way, the rest agree
+            big = p.grad.abs() > 1e-3 * p.grad.abs().max()
+            assert torch.allclose(p[big], q[big], rtol=0, atol=1e-4), k
+            moved += int(big.sum())
+        assert moved > 1000
+        # a second backward with no finish() / zero_grad() between is refused instead of silently racing a collective
+        with pytest.raises(RuntimeError):
+            (-synced.log_prob(x).mean()).backward()
+            (-synced.log_prob(x).mean()).backward()
+    finally:
+        nf.set_matmul_dtype('f32')

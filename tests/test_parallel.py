@@ -232,3 +232,117 @@ def test_gradient_synchronizer_single_process_views():
     sync.finish()
     for p, r in zip(model.parameters(), ref):
         assert torch.equal(p.grad, r) and p.grad.data_ptr() == sync._bucket_of[p][1].data_ptr()
+
+
+def _bn_worker(rank, world, port, affine, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from normalizing_flows_amd import parallel
+        torch.set_num_threads(1)
+        x, g = _bn_data()
+        lo, hi = parallel.shard_bounds(x.shape[0], rank, world)
+        bn = parallel.convert_sync_batchnorm(torch.nn.Sequential(_bn_module(affine)))[0].train()
+        xs = x[lo:hi].clone().requires_grad_(True)
+        y = bn(xs)
+        (y * g[lo:hi]).sum().backward()
+        torch.save({'y': y.detach(), 'gx': xs.grad, 'mean': bn.running_mean, 'var': bn.running_var,
+                    'gw': None if not affine else bn.weight.grad, 'gb': None if not affine else bn.bias.grad}, out % rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def _bn_data():
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(50, 5, generator=gen)
+    x[:, 0] = x[:, 0] * 0.1 + 100.0           # |mean| >> std: E[x^2] - mean^2 in fp32 keeps no digit of this variance
+    x[:, 1] = x[:, 1] * 1e-2 - 3000.0
+    return x, torch.randn(50, 5, generator=gen)
+
+
+def _bn_module(affine):
+    torch.manual_seed(4)
+    bn = torch.nn.BatchNorm1d(5, eps=1e-3, affine=affine)
+    if affine:
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-1, 1)
+    return bn
+
+
+@pytest.mark.parametrize('affine', [True, False])
+def test_two_rank_sync_batchnorm_with_a_large_mean_feature(tmp_path, affine):
+    """fp32 SyncBatchNorm1d on 2 ranks x 25 rows against nn.BatchNorm1d on the 50 rows, with features whose mean is
+    1e3-3e5 standard deviations from zero (the uncentred fp32 variance collapsed to 0 there), and with
+    affine=False (weight / bias None)."""
+    out = str(tmp_path / 'bn%d.pt')
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_bn_worker, args=(2, port, affine, out), nprocs=2, join=True)
+    got = [torch.load(out % r) for r in range(2)]
+    x, g = _bn_data()
+    bn = _bn_module(affine).double().train()             # the float64 truth; fp32 inputs are exact in it
+    xr = x.double().requires_grad_(True)
+    y = bn(xr)
+    (y * g.double()).sum().backward()
+    y_got = torch.cat([got[0]['y'], got[1]['y']]).double()
+    gx_got = torch.cat([got[0]['gx'], got[1]['gx']]).double()
+    # what fp32 can hold: x - mean is exact, the mean itself is rounded to fp32 (half an ulp of |mean|), and that
+    # offset is divided by sqrt(var + eps); everything else is 1e-6 relative
+    sd = (x.double().var(0, unbiased=False) + 1e-3).sqrt()
+    tol = 1e-5 + 2.0 ** -23 * x.double().mean(0).abs() / sd * (1.5 if affine else 1.0)
+    assert ((y_got - y.detach()).abs().max(0).values <= tol).all(), ((y_got - y.detach()).abs().max(0).values, tol)
+    assert torch.allclose(gx_got, xr.grad, rtol=1e-3, atol=1e-3 * xr.grad.abs().max().item())
+    for r in range(2):
+        assert torch.allclose(got[r]['mean'].double(), bn.running_mean, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(got[r]['var'].double(), bn.running_var, rtol=1e-5, atol=1e-8)
+    assert torch.equal(got[0]['mean'], got[1]['mean']) and torch.equal(got[0]['var'], got[1]['var'])
+    if affine:                                 # parameter gradients stay local sums; their sum is the global gradient
+        assert torch.allclose((got[0]['gw'] + got[1]['gw']).double(), bn.weight.grad, rtol=1e-3, atol=2e-2)
+        assert torch.allclose((got[0]['gb'] + got[1]['gb']).double(), bn.bias.grad, rtol=1e-4, atol=1e-4)
+
+
+def _accum_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from normalizing_flows_amd import parallel
+        torch.set_num_threads(1)
+        model = _dp_model(False)
+        x = torch.randn(64, 6, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+        lo, hi = parallel.shard_bounds(64, rank, world)
+        mid = (lo + hi) // 2
+        sync = parallel.GradientSynchronizer(model.parameters(), bucket_bytes=1024)
+        sync.zero_grad()
+        _dp_loss(model, x[lo:mid]).backward()
+        raised = False
+        try:
+            _dp_loss(model, x[mid:hi]).backward()          # a second backward with the collectives under way
+        except RuntimeError as e:
+            raised = 'no_sync' in str(e)
+        sync.finish()
+        sync.zero_grad()
+        with sync.no_sync():
+            _dp_loss(model, x[lo:mid]).backward()
+        _dp_loss(model, x[mid:hi]).backward()
+        sync.finish()
+        if rank == 0:
+            torch.save({'raised': raised, 'grads': [p.grad.clone() for p in model.parameters()]}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_synchronizer_second_backward_raises_and_no_sync_accumulates(tmp_path):
+    out = str(tmp_path / 'acc.pt')
+    port = 39500 + (os.getpid() % 2000)
+    mp.spawn(_accum_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got['raised']
+    model = _dp_model(False)
+    x = torch.randn(64, 6, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    # four micro-batches of 16 rows: each rank sums its two, the all-reduce averages the ranks
+    total = sum(_dp_loss(model, x[s:s + 16]) for s in range(0, 64, 16)) / 2
+    total.backward()
+    for g, p in zip(got['grads'], model.parameters()):
+        assert torch.allclose(g, p.grad, rtol=1e-10, atol=1e-12)

@@ -69,3 +69,38 @@ def test_noalloc_entry_point_equals_workspace_entry_point(mode):
                                        x.data_ptr(), D, y.data_ptr(), D, lad.data_ptr(), 0, None, too_many, H, D, K, 1,
                                        Tb, 1e-3, 1e-3, 1e-3, 0, dtype, None) == -6
     assert b'8 MiB' in lib.nf_strerror(-6)
+
+
+def test_noalloc_split_mode_when_the_term_planes_do_not_fit():
+    """NF_DTYPE_F16X2 at H = 512, B = 8192: the pre-split term planes of the hidden state (2 x B x 512 x 2 bytes = 16 MiB)
+    do not fit the 8 MiB static array, so the call takes the kernel that splits the hidden state inside its K loop
+    instead of the eight-wave plane kernel - another accumulation order.  What holds there (include/nf_hip.h): bit
+    equality with nf_made_rqs_fwd given a workspace of the same 8 MiB (the path is chosen from the workspace size
+    alone), and the 1e-5 contract against the plane path a full workspace selects."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from normalizing_flows_amd import _lib
+    lib = _lib.load()
+    D, H, K, Tb, B = 40, 512, 8, 3.0, 8192
+    sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=12, scale=0.05)
+    w, m, b = (sd['autoregressive_net.final_layer.' + k].cuda() for k in ('weight', 'mask', 'bias'))
+    pf = _lib.PackedFusedFinal(w, m, b, D, K, 'linear', _lib.NF_DTYPE_F16X2)
+    assert lib.nf_made_rqs_workspace_bytes_dtype(B, D, H, K, 1, _lib.NF_DTYPE_F16X2) > (8 << 20)     # planes do not fit
+    g = torch.Generator().manual_seed(6)
+    for rows in (B, 3000):                               # the second call is smaller
+        h = torch.randn(rows, H, generator=g).relu().cuda()
+        x = (torch.randn(rows, D, generator=g) * 1.4).cuda()
+        y = torch.full_like(x, float('nan'))
+        lad = torch.full((rows,), float('nan'), device='cuda')
+        assert _call_noalloc(lib, pf, h, x, y, lad, None, K, Tb) == 0
+        ws = torch.empty((8 << 20) // 4, dtype=torch.float32, device='cuda')
+        y2, lad2 = torch.empty_like(x), torch.empty_like(lad)
+        assert lib.nf_made_rqs_fwd(h.data_ptr(), H, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(),
+                                   x.data_ptr(), D, y2.data_ptr(), D, lad2.data_ptr(), 0, None, ws.data_ptr(),
+                                   ws.numel() * 4, rows, H, D, K, 1, Tb, 1e-3, 1e-3, 1e-3, 0, pf.dtype,
+                                   torch.cuda.current_stream().cuda_stream) == 0
+        assert torch.equal(y, y2) and torch.equal(lad, lad2)
+        y3, lad3, _ = _lib.made_rqs(h, pf, x, Tb)        # full workspace: the plane kernel (when rows' planes fit 8 MiB
+        for got, ref in ((y, y3), (lad, lad3)):          # both took it and this is equality again)
+            e = ((got - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+            assert e <= 1e-5, e
