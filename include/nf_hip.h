@@ -226,7 +226,7 @@ int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h
  * for NF_DTYPE_F16X2 / BF16X3 the kernel is chosen from the workspace size - when the hidden state's pre-split term
  * planes (terms * B * kpad(in) * 2 bytes beside the partials; in = 512: B <= ~3900) fit the array the plane kernel
  * runs, past that the kernel that splits the hidden state inside its K loop (slower, another accumulation order:
- * equal to the plane kernel's results within the 1e-5 contract, not bit for bit). */
+ * both meet the same contract against the reference, they are not equal bit for bit). */
 int nf_made_rqs_fwd_noalloc(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
                             const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
                             int64_t y_row_stride, float* logabsdet, int accumulate, int32_t* bin_idx, int64_t B, int in,

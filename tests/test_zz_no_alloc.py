@@ -76,7 +76,7 @@ def test_noalloc_split_mode_when_the_term_planes_do_not_fit():
     do not fit the 8 MiB static array, so the call takes the kernel that splits the hidden state inside its K loop
     instead of the eight-wave plane kernel - another accumulation order.  What holds there (include/nf_hip.h): bit
     equality with nf_made_rqs_fwd given a workspace of the same 8 MiB (the path is chosen from the workspace size
-    alone), and the 1e-5 contract against the plane path a full workspace selects."""
+    alone), and the fp32 contract against the oracle, which the plane path a full workspace selects meets too."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     from normalizing_flows_amd import _lib
@@ -100,7 +100,17 @@ def test_noalloc_split_mode_when_the_term_planes_do_not_fit():
                                    ws.numel() * 4, rows, H, D, K, 1, Tb, 1e-3, 1e-3, 1e-3, 0, pf.dtype,
                                    torch.cuda.current_stream().cuda_stream) == 0
         assert torch.equal(y, y2) and torch.equal(lad, lad2)
-        y3, lad3, _ = _lib.made_rqs(h, pf, x, Tb)        # full workspace: the plane kernel (when rows' planes fit 8 MiB
-        for got, ref in ((y, y3), (lad, lad3)):          # both took it and this is equality again)
-            e = ((got - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
-            assert e <= 1e-5, e
+        # against the reference arithmetic (the rule of test_gpu_parity.py::assert_close): 1e-5 of the oracle's fp64
+        # result on 99 % of the elements, everywhere within 4x the oracle's own fp32-vs-fp64 distance - for this path
+        # and for the plane path a full workspace selects (another accumulation order: they differ from each other by
+        # as much as either differs from the oracle on the ill-conditioned elements)
+        y3, lad3, _ = _lib.made_rqs(h, pf, x, Tb)
+        pm = (w * m).cpu()
+        p64 = h.cpu().double() @ pm.double().t() + b.cpu().double()
+        ref_y, ref_lad = O._rq_ar_elementwise(x.cpu().double(), p64, K, Tb, False, (1e-3, 1e-3, 1e-3))
+        y32, lad32 = O._rq_ar_elementwise(x.cpu(), h.cpu() @ pm.t() + b.cpu(), K, Tb, False, (1e-3, 1e-3, 1e-3))
+        for got, ref, ref32 in ((y, ref_y, y32), (lad, ref_lad, lad32), (y3, ref_y, y32), (lad3, ref_lad, lad32)):
+            e = (got.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)
+            floor = ((ref32.double() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+            assert e.max().item() <= max(1e-5, 4 * floor), (e.max().item(), floor)
+            assert (e <= 1e-5).double().mean().item() >= 0.99
