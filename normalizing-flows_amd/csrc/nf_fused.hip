@@ -18,6 +18,8 @@
 // lifetime) and its barrier phases issue no MFMA; with four barrier domains per SIMD the other three keep
 // the matrix pipe busy meanwhile (measured with the NF_STAMP phase clocks: two 512-thread workgroups per
 // CU left the pipe idle 30 % of the time, benchmarks/diag_stamp.py).
+#include <stdlib.h>
+#include <string.h>
 #include "nf_common.h"
 #include "nf_rqs_eval.h"
 
@@ -68,6 +70,7 @@ struct FusedArgs {
     int64_t M;
     int K, D;
     int fpt;                 // features per tile
+    unsigned fpt_magic;      // ceil(2^20 / fpt): i / fpt == (i * fpt_magic) >> 20 for i < 2^13 (the t kernels' tile indices)
     int n_tiles;             // column tiles computed by this launch, starting at tn0 (window)
     int tn0;
     int feat_limit;          // features >= feat_limit are left untouched (incremental inverse); D = all
@@ -82,20 +85,23 @@ struct FusedArgs {
 };
 
 __device__ __forceinline__ void tile_of_block(const FusedArgs& g, int64_t& tm, int& tn) {
-    const int64_t nwg = (int64_t)gridDim.x;
-    const int64_t bid = blockIdx.x;
-    const int64_t q = nwg / 8, r = nwg % 8;
-    const int64_t xcd = bid % 8;
-    const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    const int64_t per_group = (int64_t)g.group_m * g.n_tiles;
-    const int64_t grp = wg / per_group;
-    const int64_t first_m = grp * g.group_m;
-    const int64_t gm = min((int64_t)g.group_m, g.m_tiles - first_m);
-    const int64_t in = wg - grp * per_group;
-    tm = first_m + in % gm;
+    // (32-bit arithmetic: the host refuses grids of 2^31 workgroups or more; the 64-bit divisions this replaced were
+    // some 2000 cycles of every workgroup's prologue)
+    const unsigned nwg = gridDim.x;
+    const unsigned bid = blockIdx.x;
+    const unsigned q = nwg / 8, r = nwg % 8;
+    const unsigned xcd = bid % 8;
+    const unsigned wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    const unsigned per_group = (unsigned)g.group_m * (unsigned)g.n_tiles;
+    const unsigned grp = wg / per_group;
+    const unsigned first_m = grp * g.group_m;
+    const unsigned gm = min((unsigned)g.group_m, (unsigned)g.m_tiles - first_m);
+    const unsigned in = wg - grp * per_group;
+    const unsigned col = in / gm;
+    tm = first_m + (in - col * gm);
     // heaviest column tiles first: with triangular masks the K extent grows with the tile index, and
     // starting the long workgroups early leaves the short ones to fill the tail of the launch
-    tn = g.n_tiles - 1 - (int)(in / gm) + g.tn0;
+    tn = g.n_tiles - 1 - (int)col + g.tn0;
 }
 
 // ---- operand staging (fp32 / bf16 flavours share the kernel skeleton through this trait) -------------
@@ -561,6 +567,12 @@ static void launch_ktab_fused(const float* mask, int out, int in, int src_rows, 
 #endif
 #ifndef NF_KO_OUT
 #define NF_KO_OUT 0
+#endif
+#ifndef NF_EPI_PRIO
+#define NF_EPI_PRIO 0
+#endif
+#ifndef NF_F16X2_DEFAULT_FLAVOUR
+#define NF_F16X2_DEFAULT_FLAVOUR 4          // (see w8_flavour)
 #endif
 constexpr int XM = 128, XT = 256, XS = 16;     // samples per workgroup, threads, K elements per step
 // LDS stage = NT term planes of A [128 rows][32 B], rows unpadded; the two 16-byte halves of a row are
@@ -1797,16 +1809,24 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-constexpr int YFP = 4;                               // features per epilogue pass: 8 waves = 4 features x 2 row halves
-constexpr int YLDT = YM + 4;                         // column-major parameter tile of a pass: [4 P columns][128 + 4]
-__host__ __device__ inline int w8_ring_bytes(int P) {
-    const int tile = YFP * P * YLDT * 4;             // epilogue tile (aliases the stages)
-    return (tile > YNS * YSTAGE ? tile : YNS * YSTAGE + 15) / 16 * 16;
+constexpr int YFP = 4;                               // features per epilogue pass: waves = 4 features x (2 RT) row groups of 64
+// RT = row tiles of 128 samples per workgroup.  RT = 1: 512 threads on 128 x 256 outputs, two workgroups per CU (one's
+// epilogue under the other's K loop).  RT = 2 (round 3): 1024 threads on 256 x 256, ONE workgroup per CU, every B stage
+// shared by two row tiles: 32 KB instead of 2 x 24 KB of operands through L2 -> LDS per K step and 256 rows.  Knock-out
+// builds of the RT = 1 kernel (benchmarks/ab_fused.sh, profiles/r03_a_knockouts.jsonl) showed why: with the MFMAs AND
+// the spline evaluation removed the launch still took 2.8 of its 5.65 ms - the LDS-DMA stream alone, 38 GB at the
+// 13.7 TB/s this device moves from L2 into its CUs - and 3.8 ms with the DMA removed instead: the K loop was bound
+// by the operand stream (24 KB per 768 MFMA cycles and CU), then by power.
+__host__ __device__ inline int w8_stage_bytes(int rt) { return rt * YA_BYTES + YB_BYTES; }
+__host__ __device__ inline int w8_ring_bytes(int P, int rt = 1) {
+    const int tile = YFP * P * (YM * rt + 4) * 4;    // epilogue tile [4 P columns][rows + 4] (aliases the stages)
+    const int ring = YNS * w8_stage_bytes(rt);
+    return (tile > ring ? tile : ring + 15) / 16 * 16;
 }
-__host__ __device__ inline int w8_xs_bytes(int fpt) { return (YM * fpt + 63) / 64 * 256; }   // whole 64-element DMA pieces
+__host__ __device__ inline int w8_xs_bytes(int fpt, int rt = 1) { return (YM * rt * fpt + 63) / 64 * 256; }   // whole 64-element DMA pieces
 
 __device__ __forceinline__ void wait_vmcnt(int n) {          // counted wait with a wave-uniform runtime count
-    switch (n) {
+    switch (n) {                                             // (a count above the last case waits for more than asked: safe)
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
@@ -1816,25 +1836,42 @@ __device__ __forceinline__ void wait_vmcnt(int n) {          // counted wait wit
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
     }
 }
 
-template <int KT, bool INV>
-__global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArgs g) {
+template <int KT, bool INV, int RT>
+__global__ __launch_bounds__(YT * RT, 4) void made_rqs_f16x2_w8_kernel(const FusedArgs g) {
     typedef SplitF16x2 SP;
     typedef SP::vec vec;
+    constexpr int NTH = YT * RT, NW = NTH / 64;              // threads, waves (8 or 16)
+    constexpr int ROWS = YM * RT, LDTR = ROWS + 4;           // samples per workgroup, stride of the epilogue tile
+    constexpr int RG = 2 * RT;                               // row groups of 64 (= waves per feature in an epilogue pass)
+    constexpr int STAGE = RT * YA_BYTES + YB_BYTES;
+    constexpr int BPW = 16 / NW;                             // B pieces a wave moves per K step (2 or 1), + one A piece
+    constexpr int LPS = 1 + BPW;                             // LDS-DMA instructions per wave and K step
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int fpt = g.fpt, P = g.c.P;
-    const int ring = w8_ring_bytes(P);
-    float* tile = (float*)lds;                               // epilogue: [4 P][YLDT], aliases the stages
-    float* xs = (float*)(lds + ring);                        // [128][fpt] inputs, overwritten by outputs
+    const int ring = w8_ring_bytes(P, RT);
+    float* tile = (float*)lds;                               // epilogue: [4 P][LDTR], aliases the stages
+    float* xs = (float*)(lds + ring);                        // [ROWS][fpt] inputs, overwritten by outputs
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
     int64_t tm;
     int tn;
     tile_of_block(g, tm, tn);
-    const int64_t m0 = tm * YM;
+    const int64_t m0 = tm * ROWS;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wq = w & 3;
@@ -1843,6 +1880,7 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
 #ifdef NF_STAMP
     long long sp_[12], t_dma = 0, t_bar = 0;
     int spn = 0;
+    const long long rt0_ = __builtin_amdgcn_s_memrealtime();
 #define YSTAMP() { __builtin_amdgcn_sched_barrier(0); sp_[spn++] = clock64(); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define YSTAMP()
@@ -1853,15 +1891,18 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
     const int kt_begin = g.ktab[2 * tn];
     const int kt_end = min(g.ktab[2 * tn + 1], ksteps);
 
-    // per step a wave moves A piece w (of 8) and B pieces w, w + 8 (of 16)
-    const char* asrc = (const char*)g.hp + ((int64_t)tm * (g.hp_ld / XS)) * YA_BYTES + w * 1024 + lane * 16;
+    // per step wave w moves A piece w (of 8 RT: piece w & 7 of the workgroup's 128-row tile w >> 3; a tile past the
+    // end of an odd batch re-reads the last one, its rows are never stored) and B pieces w (+ 8) of 16
+    const int64_t tiles128 = (g.M + YM - 1) / YM;
+    const int64_t at = min(tm * RT + (w >> 3), tiles128 - 1);
+    const char* asrc = (const char*)g.hp + (at * (g.hp_ld / XS)) * YA_BYTES + (w & 7) * 1024 + lane * 16;
     const char* bsrc = (const char*)g.w + ((int64_t)tn * (g.kpad / XS)) * YB_BYTES + w * 1024 + lane * 16;
     auto issue = [&](int kt, int st) {
         if (NF_KO_LOADS) return;
-        const unsigned dst = lds_base + st * YSTAGE + w * 1024;
+        const unsigned dst = lds_base + st * STAGE + w * 1024;
         glds16(asrc + (int64_t)kt * YA_BYTES, dst);
-        glds16b(bsrc + (int64_t)kt * YB_BYTES, dst + YA_BYTES);
-        glds16b(bsrc + (int64_t)kt * YB_BYTES + 8192, dst + YA_BYTES + 8192);
+        glds16b(bsrc + (int64_t)kt * YB_BYTES, dst + RT * YA_BYTES);
+        if (BPW == 2) glds16b(bsrc + (int64_t)kt * YB_BYTES + 8192, dst + RT * YA_BYTES + 8192);
     };
 #pragma unroll
     for (int q = 0; q < YNS - 1; ++q)
@@ -1872,8 +1913,8 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
     // first read in the epilogue, so they must not hold up the first K steps (loads retire in order)
     int nxp = 0;                                                   // pieces this wave issued
     {
-        const int nx = YM * fpt;
-        for (int pc = w; pc * 64 < nx; pc += YT / 64) {
+        const int nx = ROWS * fpt;
+        for (int pc = w; pc * 64 < nx; pc += NW) {
             const int i = min(pc * 64 + lane, nx - 1);
             const int r = i / fpt, f = min(i - r * fpt, fv - 1);
             const int64_t row = min(m0 + r, g.M - 1);
@@ -1894,21 +1935,22 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment offsets inside a stage
+    // fragment offsets inside a stage: the A image is [128-row tile][term][slot = 2 row + (half ^ bit 3 of the row)][16 B]
     const int frow = lane & 31;
-    const int aoff = ((wr * 64 + frow) * 2 + ((lane >> 5) ^ ((frow >> 3) & 1))) * 16;      // + i * 1024 + p * 4096
-    const int boff = YA_BYTES + wq * 4096 + lane * 16;                                     // + (j * 2 + p) * 1024
+    const int arow = (wr & 1) * 64 + frow;                                                 // row inside its 128-row tile
+    const int aoff = (wr >> 1) * YA_BYTES + (arow * 2 + ((lane >> 5) ^ ((frow >> 3) & 1))) * 16;   // + i * 1024 + p * 4096
+    const int boff = RT * YA_BYTES + wq * 4096 + lane * 16;                                // + (j * 2 + p) * 1024
     YSTAMP()
 
     int st = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        // own pieces of step kt landed; what was issued after them may stay in flight: the later steps' pieces (3 each)
-        // and, while the prologue's steps are being consumed, the input pieces issued behind the prologue
+        // own pieces of step kt landed; what was issued after them may stay in flight: the later steps' pieces (LPS
+        // each) and, while the prologue's steps are being consumed, the input pieces issued behind the prologue
         const int later = min(YNS - 2, kt_end - 1 - kt);
 #ifdef NF_STAMP
         const long long q0 = clock64();
 #endif
-        wait_vmcnt(3 * later + (kt - kt_begin < pro ? nxp : 0));
+        wait_vmcnt(LPS * later + (kt - kt_begin < pro ? nxp : 0));
 #ifdef NF_STAMP
         const long long q1 = clock64();
 #endif
@@ -1919,7 +1961,7 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
         t_bar += clock64() - q1;
 #endif
         if (kt + YNS - 1 < kt_end) issue(kt + YNS - 1, st == 0 ? YNS - 1 : st - 1);
-        const char* sp = lds + st * YSTAGE;
+        const char* sp = lds + st * STAGE;
         vec a[2][2], b[2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -1941,13 +1983,14 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the inputs' DMA when there was no K step at all)
     YSTAMP()
 
-    // ---- epilogue: passes of 4 features x all 128 samples; every wave hands over the columns it holds of the pass's
-    //      features, then evaluates ONE (feature, row half) - the same amount of spline work in every wave -------------
+    // ---- epilogue: passes of 4 features x all rows; every wave hands over the columns it holds of the pass's
+    //      features, then evaluates ONE (feature, 64-row group) - the same amount of spline work in every wave ---------
     float ws = 1.f, wi = 1.f, hs = 1.f, hi = 1.f;
     pow2_pair(*g.wmax, ws, wi);
     pow2_pair(*g.hmax, hs, hi);
     const float oscale = wi * hi;
-    const int r = (w & 1) * 64 + lane;                       // this lane's sample row in every pass
+    const int fl = w / RG;                                   // wave-uniform feature slot of this wave in every pass
+    const int r = (w % RG) * 64 + lane;                      // this lane's sample row in every pass
     float lsum = 0.f;
 #pragma unroll 1
     for (int f_pass = 0; f_pass < fv; f_pass += YFP) {
@@ -1957,7 +2000,7 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
         for (int j = 0; j < 2; ++j) {
             const int col = wq * 64 + j * 32 + (lane & 31);
             if (col >= c0 && col < c1) {
-                float* tp = tile + (col - c0) * YLDT + wr * 64 + 4 * (lane >> 5);
+                float* tp = tile + (col - c0) * LDTR + wr * 64 + 4 * (lane >> 5);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1970,12 +2013,12 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
             }
         }
         __syncthreads();
-        const int fl = w >> 1, f = f_pass + fl;              // wave-uniform feature of this wave
+        const int f = f_pass + fl;
         if (f < fv) {
             float yv, ld;
             int bin;
-            if (NF_KO_EVAL) { yv = tile[fl * P * YLDT + r]; ld = yv; bin = 0; }
-            else rqs_eval<KT, INV, YLDT, true, true, const float*, false>(tile + fl * P * YLDT + r, xs[r * fpt + f], g.c, yv, ld, bin);
+            if (NF_KO_EVAL) { yv = tile[fl * P * LDTR + r]; ld = yv; bin = 0; }
+            else rqs_eval<KT, INV, LDTR, true, true, const float*, false>(tile + fl * P * LDTR + r, xs[r * fpt + f], g.c, yv, ld, bin);
             xs[r * fpt + f] = yv;
             lsum += ld;
 #ifndef NF_STAMP
@@ -1985,15 +2028,15 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
     }
     YSTAMP()
     __syncthreads();
-    float* ldp = tile;                                       // [4 feature slots][128]: the tile is dead now
-    ldp[(w >> 1) * YM + r] = lsum;
+    float* ldp = tile;                                       // [4 feature slots][ROWS]: the tile is dead now
+    ldp[fl * ROWS + r] = lsum;
     __syncthreads();
-    if (tid < YM) {
-        const float s = ((ldp[tid] + ldp[YM + tid]) + ldp[2 * YM + tid]) + ldp[3 * YM + tid];      // fixed order
+    if (tid < ROWS) {
+        const float s = ((ldp[tid] + ldp[ROWS + tid]) + ldp[2 * ROWS + tid]) + ldp[3 * ROWS + tid];      // fixed order
         if (m0 + tid < g.M) g.partial[(int64_t)tn * g.M + m0 + tid] = s;
     }
     float ymax = 0.f;
-    for (int i = tid; i < YM * fpt; i += YT) {
+    for (int i = tid; i < ROWS * fpt; i += NTH) {
         const int rr = i / fpt, f = i - rr * fpt;
         if (m0 + rr < g.M && f < fv) {
             const float v = xs[i];
@@ -2010,16 +2053,307 @@ __global__ __launch_bounds__(YT, 4) void made_rqs_f16x2_w8_kernel(const FusedArg
 #ifdef NF_STAMP
     YSTAMP()
     if (g.bins && lane == 0) {
-        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * (YT / 64) + w) * 16;
+        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * NW + w) * 16;
         for (int i = 0; i < 5; ++i) dbg[i] = sp_[i];
         dbg[8] = kt_end - kt_begin;
         dbg[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         dbg[10] = tn;
         dbg[11] = t_dma;
         dbg[12] = t_bar;
+        dbg[13] = __builtin_amdgcn_s_memrealtime() - rt0_;
     }
 #endif
 #undef YSTAMP
+}
+
+// ======================================================================================================
+// "t" flavours (round 3): the same fused layer with waves of 128 x 64 (128 accumulator registers per lane, two waves
+// per SIMD) and - what the register budget of the 64 x 64-wave kernels above has no room for - TWO sets of operand
+// fragments: the fragments of K step k+1 are read from LDS, and the LDS-DMA of step k+3 is issued, BETWEEN the MFMAs
+// of step k, two items per accumulator tile, so that no MFMA waits on an LDS read and the issue slots of the loads sit
+// under the matrix pipe's own cycles.  (In-kernel stamps of the kernels above, benchmarks/diag_stamp_w8.py: per K step
+// a wave spends 1340-1400 ticks on issue + reads + its MFMAs and 370-900 at the barrier, against 768 / 1536 cycles of
+// MFMA work per SIMD: after every barrier all waves of a workgroup issue their DMA pieces and fragment reads at the
+// same time, and the matrix pipe idles until the first fragments are back.)
+//   RT = 1 ("t4"): 256 threads, four waves side by side on 128 x 256 outputs, TWO workgroups per CU - every SIMD holds
+//           one wave of each, so one workgroup's spline epilogue runs under the other's K loop;
+//   RT = 2 ("t8"): 512 threads, 2 x 4 waves on 256 x 256, one workgroup per CU, every B stage shared by two row tiles
+//           (32 KB instead of 48 KB through L2 -> LDS per K step and 256 rows).
+// Stages: ring of 3 x (RT x 8 + 16) KB; the fragments of stage k are in registers before barrier k (lgkmcnt(0) in
+// front of the barrier makes that formal), so the DMA of step k+3 goes into its slot right behind that barrier.
+// Epilogue: passes of 4 features x all rows through the (idle) ring, two (feature, 64-row group) evaluations per wave
+// as ONE basic block.  Results equal the kernels above bit for bit (same products in the same order per element).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_c() {
+    static_assert(N == 4 || N == 6, "counts of the t kernels");
+    if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
+template <int KT, bool INV, int RT>
+__global__ __launch_bounds__(256 * RT, 2) void made_rqs_f16x2_t_kernel(const FusedArgs g) {
+    typedef SplitF16x2 SP;
+    typedef SP::vec vec;
+    constexpr int NTH = 256 * RT, NW = 4 * RT, ROWS = YM * RT, LDTR = ROWS + 4;
+    constexpr int STAGE = RT * YA_BYTES + YB_BYTES;
+    constexpr int LPS = 2 + 16 / NW;                         // LDS-DMA instructions per wave and K step (6 or 4)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int fpt = g.fpt, P = g.c.P;
+    const int ring = w8_ring_bytes(P, RT);
+    float* tile = (float*)lds;                               // epilogue: [4 P][LDTR], aliases the stages
+    float* xs = (float*)(lds + ring);                        // [ROWS][fpt] inputs, overwritten by outputs
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    int64_t tm;
+    int tn;
+    tile_of_block(g, tm, tn);
+    const int64_t m0 = tm * ROWS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wq = w & 3;                       // rows wr * 128 .. + 128, columns wq * 64 .. + 64
+    const int f0 = tn * fpt;
+    const int fv = min(fpt, g.feat_limit - f0);
+#ifdef NF_STAMP
+    long long sp_[8];
+    int spn = 0;
+    const long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#define TSTAMP() { __builtin_amdgcn_sched_barrier(0); sp_[spn++] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TSTAMP()
+#endif
+    TSTAMP()
+
+    const int ksteps = (g.K + XS - 1) / XS;
+    const int kt_begin = g.ktab[2 * tn];
+    const int n = max(min(g.ktab[2 * tn + 1], ksteps) - kt_begin, 0);          // K steps of this tile
+
+    // per step a wave moves RT A pieces (RT = 2: piece w of both 128-row tiles; RT = 1: pieces w, w + 4 of its tile;
+    // a tile past the end of an odd batch re-reads the last one, its rows are never stored) and B pieces
+    // w, w + NW, ... of 16
+    const int64_t tiles128 = (g.M + YM - 1) / YM;
+    const int64_t at0 = min(tm * RT, tiles128 - 1), at1 = min(tm * RT + RT - 1, tiles128 - 1);
+    const char* asrc0 = (const char*)g.hp + (at0 * (g.hp_ld / XS) + kt_begin) * YA_BYTES + w * 1024 + lane * 16;
+    const char* asrc1 = (const char*)g.hp + (at1 * (g.hp_ld / XS) + kt_begin) * YA_BYTES + (RT == 2 ? w : w + 4) * 1024 + lane * 16;
+    const char* bsrc = (const char*)g.w + ((int64_t)tn * (g.kpad / XS) + kt_begin) * YB_BYTES + w * 1024 + lane * 16;
+    // first / second half of a step's pieces (they are issued between different MFMA groups)
+    auto issue_a = [&](int k, int st) {
+        if (NF_KO_LOADS) return;
+        const unsigned dst = lds_base + st * STAGE;
+        glds16(asrc0 + (int64_t)k * YA_BYTES, dst + w * 1024);
+        glds16(asrc1 + (int64_t)k * YA_BYTES, dst + (RT == 2 ? YA_BYTES + w * 1024 : (w + 4) * 1024));
+        if (RT == 1) glds16b(bsrc + (int64_t)k * YB_BYTES, dst + YA_BYTES + w * 1024);
+    };
+    auto issue_b = [&](int k, int st) {
+        if (NF_KO_LOADS) return;
+        const unsigned dst = lds_base + st * STAGE + RT * YA_BYTES + w * 1024;
+        if (RT == 2) {
+            glds16b(bsrc + (int64_t)k * YB_BYTES, dst);
+            glds16b(bsrc + (int64_t)k * YB_BYTES + 8192, dst + 8192);
+        } else {
+            glds16b(bsrc + (int64_t)k * YB_BYTES + 4096, dst + 4096);
+            glds16b(bsrc + (int64_t)k * YB_BYTES + 8192, dst + 8192);
+            glds16b(bsrc + (int64_t)k * YB_BYTES + 12288, dst + 12288);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (q < n) { issue_a(q, q); issue_b(q, q); }
+
+    // inputs of the tile, straight into LDS (4-byte LDS-DMA, 64 elements per piece), BEHIND the first stages
+    int nxp = 0;                                                   // pieces this wave issued
+    {
+        const int nx = ROWS * fpt;
+        for (int pc = w; pc * 64 < nx; pc += NW) {
+            const int i = min(pc * 64 + lane, nx - 1);
+            const int r = (int)(((unsigned)i * g.fpt_magic) >> 20), f = min(i - r * fpt, fv - 1);
+            const int64_t row = min(m0 + r, g.M - 1);
+            glds4(g.x + row * g.ldx + (g.feat_index ? g.feat_index[f0 + f] : f0 + f), lds_base + ring + pc * 256);
+            ++nxp;
+        }
+    }
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[j] = g.bias[tn * FN + wq * 64 + j * 32 + (lane & 31)];
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment offsets inside a stage: A image [128-row tile][term][slot = 2 row + (half ^ bit 3 of the row)][16 B]
+    const int frow = lane & 31;
+    const int aoff = wr * YA_BYTES + (frow * 2 + ((lane >> 5) ^ ((frow >> 3) & 1))) * 16;   // + i * 1024 + p * 4096
+    const int boff = RT * YA_BYTES + wq * 4096 + lane * 16;                                 // + (j * 2 + p) * 1024
+
+#define T_SB() __builtin_amdgcn_sched_barrier(0);
+#define T_RDB(B_, j_) { B_[j_][0] = *reinterpret_cast<const vec*>(spn_ + boff + ((j_) * 2) * 1024);                 \
+                        B_[j_][1] = *reinterpret_cast<const vec*>(spn_ + boff + ((j_) * 2 + 1) * 1024); }
+#define T_RDA(A_, i_) { A_[i_][0] = *reinterpret_cast<const vec*>(spn_ + aoff + (i_) * 1024);                       \
+                        A_[i_][1] = *reinterpret_cast<const vec*>(spn_ + aoff + (i_) * 1024 + 4096); }
+#define T_FT(A_, B_, i_, j_)                                                                               \
+    T_SB()                                                                                                 \
+    if (!NF_KO_MMA) SP::fma_tile(acc[i_][j_], A_[i_], B_[j_]);                                             \
+    else acc[i_][j_][0] += (float)A_[i_][0][0] + (float)B_[j_][1][1];                                      \
+    T_SB()
+    // one K step: the fragments of step k are in (CA, CB).  Behind the barrier that publishes stage k + 1 (and frees
+    // the slot of stage k): the DMA of step k + 3 and the fragment reads of step k + 1 into (NA, NB), two items
+    // between consecutive accumulator tiles of step k (the six DMA instructions in two groups of three: one per tile,
+    // spread over six tiles, measured 3 % slower).
+#define T_STEP(CA, CB, NA, NB)                                                                             \
+    {                                                                                                      \
+        const bool more = k + 1 < n, dma = k + 3 < n;                                                      \
+        const int sn = st == 2 ? 0 : st + 1;                                                               \
+        const char* spn_ = lds + sn * STAGE;                                                               \
+        if (more) {                                                                                        \
+            if (k <= 1) wait_vmcnt((k + 2 < n ? LPS : 0) + nxp);                                           \
+            else if (k + 2 < n) wait_vmcnt_c<LPS>();                                                       \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+            __builtin_amdgcn_s_barrier();                                                                  \
+        }                                                                                                  \
+        if (dma) issue_a(k + 3, st);                                                                       \
+        T_FT(CA, CB, 0, 0)                                                                                 \
+        if (dma) issue_b(k + 3, st);                                                                       \
+        T_FT(CA, CB, 1, 0)                                                                                 \
+        if (more) T_RDB(NB, 0)                                                                             \
+        T_FT(CA, CB, 2, 0)                                                                                 \
+        if (more) T_RDB(NB, 1)                                                                             \
+        T_FT(CA, CB, 3, 0)                                                                                 \
+        if (more) T_RDA(NA, 0)                                                                             \
+        T_FT(CA, CB, 0, 1)                                                                                 \
+        if (more) T_RDA(NA, 1)                                                                             \
+        T_FT(CA, CB, 1, 1)                                                                                 \
+        if (more) T_RDA(NA, 2)                                                                             \
+        T_FT(CA, CB, 2, 1)                                                                                 \
+        if (more) T_RDA(NA, 3)                                                                             \
+        T_FT(CA, CB, 3, 1)                                                                                 \
+        st = sn;                                                                                           \
+        ++k;                                                                                               \
+    }
+
+    vec a0[4][2], b0[2][2], a1[4][2], b1[2][2];
+    int k = 0, st = 0;
+    TSTAMP()
+    if (n > 0) {
+        wait_vmcnt(LPS * min(2, n - 1) + nxp);                // own pieces of step 0
+        __builtin_amdgcn_s_barrier();                         // ... and everybody's
+        {
+            const char* spn_ = lds;
+            T_RDB(b0, 0) T_RDB(b0, 1) T_RDA(a0, 0) T_RDA(a0, 1) T_RDA(a0, 2) T_RDA(a0, 3)
+        }
+        while (k < n) {
+            T_STEP(a0, b0, a1, b1)
+            if (k < n) T_STEP(a1, b1, a0, b0)
+        }
+    }
+#undef T_STEP
+#undef T_FT
+#undef T_RDA
+#undef T_RDB
+#undef T_SB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the inputs' DMA when there were fewer than two K steps)
+    TSTAMP()
+
+    // ---- epilogue: passes of 4 features x all rows; every wave hands over the columns it holds of the pass's
+    //      features, then evaluates TWO (feature, 64-row group) items of one feature as one basic block ---------------
+    float ws = 1.f, wi = 1.f, hs = 1.f, hi = 1.f;
+    pow2_pair(*g.wmax, ws, wi);
+    pow2_pair(*g.hmax, hs, hi);
+    const float oscale = wi * hi;
+    // items of a pass: 4 features x 2 RT row groups of 64 = 2 per wave, both of one feature
+    const int fl = RT == 2 ? w >> 1 : w;                                     // wave-uniform feature slot
+    const int r0 = (RT == 2 ? (w & 1) * 128 : 0) + lane, r1 = r0 + 64;       // this lane's two sample rows
+    float lsum0 = 0.f, lsum1 = 0.f;
+#pragma unroll 1
+    for (int f_pass = 0; f_pass < fv; f_pass += YFP) {
+        const int c0 = f_pass * P, c1 = min(f_pass + YFP, fpt) * P;
+        __syncthreads();                                     // stages / previous pass fully consumed
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wq * 64 + j * 32 + (lane & 31);
+            if (col >= c0 && col < c1) {
+                float* tp = tile + (col - c0) * LDTR + wr * 128 + 4 * (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                        v.x = v.x * oscale + bv[j]; v.y = v.y * oscale + bv[j];
+                        v.z = v.z * oscale + bv[j]; v.w = v.w * oscale + bv[j];
+                        *reinterpret_cast<float4*>(tp + i * 32 + 8 * q) = v;
+                    }
+            }
+        }
+        __syncthreads();
+        const int f = f_pass + fl;
+#if NF_EPI_PRIO
+        __builtin_amdgcn_s_setprio(NF_EPI_PRIO);             // the evaluation's VALU stream ahead of the partner workgroup's issue
+#endif
+        if (f < fv) {
+            float yv0, ld0, yv1, ld1;
+            int bin0, bin1;
+            if (NF_KO_EVAL) { yv0 = tile[fl * P * LDTR + r0]; ld0 = yv0; bin0 = 0; yv1 = tile[fl * P * LDTR + r1]; ld1 = yv1; bin1 = 0; }
+            else {
+                rqs_eval<KT, INV, LDTR, true, true, const float*, false>(tile + fl * P * LDTR + r0, xs[r0 * fpt + f], g.c, yv0, ld0, bin0);
+                rqs_eval<KT, INV, LDTR, true, true, const float*, false>(tile + fl * P * LDTR + r1, xs[r1 * fpt + f], g.c, yv1, ld1, bin1);
+            }
+            xs[r0 * fpt + f] = yv0;
+            xs[r1 * fpt + f] = yv1;
+            lsum0 += ld0;
+            lsum1 += ld1;
+#ifndef NF_STAMP
+            if (g.bins) {
+                if (m0 + r0 < g.M) g.bins[(m0 + r0) * (int64_t)g.D + f0 + f] = bin0;
+                if (m0 + r1 < g.M) g.bins[(m0 + r1) * (int64_t)g.D + f0 + f] = bin1;
+            }
+#endif
+        }
+#if NF_EPI_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+    TSTAMP()
+    __syncthreads();
+    float* ldp = tile;                                       // [4 feature slots][ROWS]: the tile is dead now
+    ldp[fl * ROWS + r0] = lsum0;
+    ldp[fl * ROWS + r1] = lsum1;
+    __syncthreads();
+    if (tid < ROWS) {
+        const float s = ((ldp[tid] + ldp[ROWS + tid]) + ldp[2 * ROWS + tid]) + ldp[3 * ROWS + tid];      // fixed order
+        if (m0 + tid < g.M) g.partial[(int64_t)tn * g.M + m0 + tid] = s;
+    }
+    float ymax = 0.f;
+    for (int i = tid; i < ROWS * fpt; i += NTH) {
+        const int rr = (int)(((unsigned)i * g.fpt_magic) >> 20), f = i - rr * fpt;
+        if (m0 + rr < g.M && f < fv) {
+            const float v = xs[i];
+            g.y[(m0 + rr) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = v;
+            const float a = fabsf(v);
+            ymax = fmaxf(ymax, a < INFINITY ? a : 0.f);
+        }
+    }
+    if (g.out_max) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+        if (lane == 0 && __float_as_uint(ymax) > __builtin_nontemporal_load(g.out_max)) atomicMax(g.out_max, __float_as_uint(ymax));
+    }
+#ifdef NF_STAMP
+    TSTAMP()
+    if (g.bins && lane == 0) {
+        long long* dbg = (long long*)g.bins + ((int64_t)blockIdx.x * NW + w) * 16;
+        for (int i = 0; i < 5; ++i) dbg[i] = sp_[i];
+        dbg[8] = n;
+        dbg[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        dbg[10] = tn;
+        dbg[11] = 0;
+        dbg[12] = 0;
+        dbg[13] = __builtin_amdgcn_s_memrealtime() - rt0_;
+    }
+#endif
+#undef TSTAMP
 }
 
 // h[M][K] fp32 -> the eight-wave kernel's A stream: [row tile of 128][K step][term][slot][8 halfs], slot = 2 * row +
@@ -2081,23 +2415,55 @@ int launch_k_split(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
     }
 }
 
-template <int KT, bool INV>
+template <int KT, bool INV, int RT>
 int launch_one_w8(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
     static unsigned long long cap_done = 0;
-    const int rc = nf_raise_lds_cap((const void*)made_rqs_f16x2_w8_kernel<KT, INV>, &cap_done);
+    const int rc = nf_raise_lds_cap((const void*)made_rqs_f16x2_w8_kernel<KT, INV, RT>, &cap_done);
     if (rc != NF_OK) return rc;
-    hipLaunchKernelGGL((made_rqs_f16x2_w8_kernel<KT, INV>), dim3(grid), dim3(YT), lds, s, g);
+    hipLaunchKernelGGL((made_rqs_f16x2_w8_kernel<KT, INV, RT>), dim3(grid), dim3(YT * RT), lds, s, g);
     return nf_launch_status();
 }
 
-template <bool INV>
+template <bool INV, int RT>
 int launch_k_w8(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
     switch (g.c.K) {
-        case 4: return launch_one_w8<4, INV>(g, grid, lds, s);
-        case 8: return launch_one_w8<8, INV>(g, grid, lds, s);
-        case 10: return launch_one_w8<10, INV>(g, grid, lds, s);
-        default: return launch_one_w8<0, INV>(g, grid, lds, s);
+        case 4: return launch_one_w8<4, INV, RT>(g, grid, lds, s);
+        case 8: return launch_one_w8<8, INV, RT>(g, grid, lds, s);
+        case 10: return launch_one_w8<10, INV, RT>(g, grid, lds, s);
+        default: return launch_one_w8<0, INV, RT>(g, grid, lds, s);
     }
+}
+
+template <int KT, bool INV, int RT>
+int launch_one_t(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+    static unsigned long long cap_done = 0;
+    const int rc = nf_raise_lds_cap((const void*)made_rqs_f16x2_t_kernel<KT, INV, RT>, &cap_done);
+    if (rc != NF_OK) return rc;
+    hipLaunchKernelGGL((made_rqs_f16x2_t_kernel<KT, INV, RT>), dim3(grid), dim3(256 * RT), lds, s, g);
+    return nf_launch_status();
+}
+
+template <bool INV, int RT>
+int launch_k_t(const FusedArgs& g, int grid, size_t lds, hipStream_t s) {
+    switch (g.c.K) {
+        case 4: return launch_one_t<4, INV, RT>(g, grid, lds, s);
+        case 8: return launch_one_t<8, INV, RT>(g, grid, lds, s);
+        case 10: return launch_one_t<10, INV, RT>(g, grid, lds, s);
+        default: return launch_one_t<0, INV, RT>(g, grid, lds, s);
+    }
+}
+
+// Which flavour of the f16x2 whole-layer kernel runs: 1 = "w8", eight waves of 64 x 64 on 128 x 256 tiles (two
+// workgroups per CU); 2 = "w16", sixteen such waves on 256 x 256; 3 = "t8", eight waves of 128 x 64 on 256 x 256 with
+// register-pipelined fragments; 4 = "t4", four such waves on 128 x 256, two workgroups per CU.
+// NF_FUSED_F16X2_KERNEL=w8|w16|t8|t4 in the environment overrides the rule (A/B runs and the tests that compare the
+// flavours: they give bit-identical results - the same products in the same order per element).
+inline int w8_flavour(int64_t B, int P, int fpt) {
+    int fl = B > 512 ? NF_F16X2_DEFAULT_FLAVOUR : 1;
+    if (const char* e = getenv("NF_FUSED_F16X2_KERNEL"))
+        fl = !strcmp(e, "w8") ? 1 : !strcmp(e, "w16") ? 2 : !strcmp(e, "t8") ? 3 : !strcmp(e, "t4") ? 4 : fl;
+    if ((fl == 2 || fl == 3) && w8_ring_bytes(P, 2) + w8_xs_bytes(fpt, 2) > 160 * 1024) fl = 1;
+    return fl;
 }
 
 // the split pre-pass (when the workspace has room for the planes and the launch covers the layer) + the kernel
@@ -2118,14 +2484,27 @@ int run_split(FusedArgs& g, int grid, size_t lds, bool pre, bool own_max, const 
         if (rc != NF_OK) return rc;
     }
     if (pre && SP::NT == 2 && w8_ring_bytes(g.c.P) + w8_xs_bytes(g.fpt) <= 160 * 1024) {
-        // f16x2, whole layer: tiled planes + the eight-wave kernel
+        // f16x2, whole layer: tiled planes + the eight-wave kernel (sixteen waves on 256-row tiles for real batches)
         const int ksteps = (int)(g.hp_ld / XS);
         const int64_t chunks = (B + YM - 1) / YM * YM * ksteps * 2;
         const int sgrid = (int)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
         hipLaunchKernelGGL(split_planes_tiled_kernel<SplitF16x2>, dim3(sgrid), dim3(256), 0, s, h, h_row_stride, B, in,
                            ksteps, g.hmax, (_Float16*)g.hp);
-        const size_t lds8 = (size_t)w8_ring_bytes(g.c.P) + w8_xs_bytes(g.fpt);
-        return inverse ? launch_k_w8<true>(g, grid, lds8, s) : launch_k_w8<false>(g, grid, lds8, s);
+        const int flavour = w8_flavour(B, g.c.P, g.fpt);
+        const int rt = flavour == 1 || flavour == 4 ? 1 : 2;
+        const size_t lds8 = (size_t)w8_ring_bytes(g.c.P, rt) + w8_xs_bytes(g.fpt, rt);
+        if (rt == 2) {
+            g.m_tiles = (B + 2 * YM - 1) / (2 * YM);
+            g.group_m = 4;
+            if (const char* e = getenv("NF_W8_GROUP_M")) g.group_m = atoi(e) > 0 ? atoi(e) : 4;
+            const int64_t grid2 = g.m_tiles * g.n_tiles;
+            if (flavour == 3)
+                return inverse ? launch_k_t<true, 2>(g, (int)grid2, lds8, s) : launch_k_t<false, 2>(g, (int)grid2, lds8, s);
+            return inverse ? launch_k_w8<true, 2>(g, (int)grid2, lds8, s) : launch_k_w8<false, 2>(g, (int)grid2, lds8, s);
+        }
+        if (flavour == 4)
+            return inverse ? launch_k_t<true, 1>(g, grid, lds8, s) : launch_k_t<false, 1>(g, grid, lds8, s);
+        return inverse ? launch_k_w8<true, 1>(g, grid, lds8, s) : launch_k_w8<false, 1>(g, grid, lds8, s);
     }
     if (pre) {
         const int64_t chunks = B * (g.hp_ld / 8);
@@ -2275,6 +2654,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
     g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max; g.vec_out = 0; g.k_reverse = 0;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
+    g.fpt_magic = ((1u << 20) + g.fpt - 1) / g.fpt;
     g.params_out = params_out; g.ldp = params_row_stride; g.unfold = (float)(logit_div * 0.6931471805599453);
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;

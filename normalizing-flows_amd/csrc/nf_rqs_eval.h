@@ -198,7 +198,13 @@ __device__ __forceinline__ void rqs_eval(PT p, float x, const RqsConst& a, float
         // last k whose left knot is <= x is that count (clamped to K-1 where the reference would index
         // past the end).
         const bool ge = INV ? (x >= kh0) : (x >= kw0);
-        if (ge) { bin = k; x0 = kw0; x1 = kw1; y0 = kh0; y1 = kh1; }
+        // (value selects, five v_cndmask: as an `if` block hipcc made this a divergent branch per knot - saveexec,
+        // branch, moves, restore - in the fused epilogues)
+        bin = ge ? k : bin;
+        x0 = ge ? kw0 : x0;
+        x1 = ge ? kw1 : x1;
+        y0 = ge ? kh0 : y0;
+        y1 = ge ? kh1 : y1;
         kw0 = kw1;
         kh0 = kh1;
     }
@@ -221,7 +227,11 @@ __device__ __forceinline__ void rqs_eval(PT p, float x, const RqsConst& a, float
 
     const float bw = x1 - x0;
     const float bh = y1 - y0;
-    const float s = bh / bw;            // IEEE division: s and t feed the cancelling terms below
+    // IEEE divisions (s and t feed the cancelling terms below); the forward direction has two over the same
+    // denominator: one refined reciprocal, then nf_div_ieee's multiply + two residual corrections each - the bits of
+    // `/` for a bin width in the normal range (>= min_bin_width * span)
+    const NfDivisor dbw = nf_divisor(bw);
+    const float s = INV ? bh / bw : nf_div_ieee(bh, dbw);
     const float curv = d0 + d1 - 2.0f * s;
     float t, den;
     if (INV) {
@@ -233,7 +243,7 @@ __device__ __forceinline__ void rqs_eval(PT p, float x, const RqsConst& a, float
         t = (2.0f * qc) / (-qb - sqrtf(disc));       // disc < 0 yields NaN (reference asserts)
         y = t * bw + x0;
     } else {
-        t = (x - x0) / bw;
+        t = nf_div_ieee(x - x0, dbw);
     }
     const float t1mt = t * (1.0f - t);
     den = s + curv * t1mt;

@@ -2533,3 +2533,48 @@ def test_gradient_synchronizer_through_the_hip_autograd_functions(nf, mode):
             (-synced.log_prob(x).mean()).backward()
     finally:
         nf.set_matmul_dtype('f32')
+
+
+@pytest.mark.parametrize('B', [513, 600, 1000, 1300])
+@pytest.mark.parametrize('inverse', [False, True])
+def test_f16x2_256_row_tile_kernels_equal_the_128_row_kernel(nf, B, inverse):
+    """The 256 x 256-tile flavours of the f16x2 fused layer (NF_FUSED_F16X2_KERNEL=w16: sixteen waves of 64 x 64;
+    =t8: eight waves of 128 x 64 with register-pipelined operand fragments; one B stage shared by two row tiles)
+    and the four-wave 128-row one with the same pipelining (=t4)
+    against the eight-wave 128-row kernel (=w8): the same products in the same order per element, so outputs,
+    logabsdet and bin indices are equal bit for bit - ragged batches whose last 256-row tile has one or no full
+    128-row half included - and they meet the oracle's bar (test_split_operand_modes_*).  K steps: H = 136 gives
+    tiles with 1..9 steps, so the three-stage ring wraps and the short-tile paths run."""
+    import os
+    from normalizing_flows_amd import _lib
+    D, H, K, Tb = 30, 136, 8, 3.0
+    sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=31, scale=0.1)
+    w, m, b = (sd['autoregressive_net.final_layer.' + k].cuda() for k in ('weight', 'mask', 'bias'))
+    pf = _lib.PackedFusedFinal(w, m, b, D, K, 'linear', _lib.NF_DTYPE_F16X2)
+    g = torch.Generator().manual_seed(B)
+    h = torch.randn(B, H, generator=g).relu().cuda()
+    x = (torch.randn(B, D, generator=g) * 1.5).cuda()
+    old = os.environ.get('NF_FUSED_F16X2_KERNEL')
+    res = {}
+    try:
+        for flavour in ('w8', 'w16', 't8', 't4', None):
+            if flavour is None:
+                os.environ.pop('NF_FUSED_F16X2_KERNEL', None)          # the library's own choice
+            else:
+                os.environ['NF_FUSED_F16X2_KERNEL'] = flavour
+            res[flavour] = _lib.made_rqs(h, pf, x, Tb, inverse=inverse, want_bins=True)
+    finally:
+        if old is None:
+            os.environ.pop('NF_FUSED_F16X2_KERNEL', None)
+        else:
+            os.environ['NF_FUSED_F16X2_KERNEL'] = old
+    y1, l1, b1 = res['w8']
+    for flavour in ('w16', 't8', 't4', None):
+        y2, l2, b2 = res[flavour]
+        assert torch.equal(y1, y2) and torch.equal(l1, l2) and torch.equal(b1, b2), flavour
+    pm = (w * m).cpu()
+    p64 = h.cpu().double() @ pm.double().t() + b.cpu().double()
+    ref_y, ref_l = O._rq_ar_elementwise(x.cpu().double(), p64, K, Tb, inverse, (1e-3, 1e-3, 1e-3))
+    y32, l32 = O._rq_ar_elementwise(x.cpu(), h.cpu() @ pm.t() + b.cpu(), K, Tb, inverse, (1e-3, 1e-3, 1e-3))
+    assert_close(y1, ref_y, y32)
+    assert_close(l1, ref_l, l32)
