@@ -15,6 +15,6 @@ from .flows import MaskedAutoregressiveFlow, SimpleMADE, SimpleMaskedLinear, app
     apply_reverse_to_samples
 from . import data
 from .data import two_moons
-from .distributions import Distribution, StandardNormal, BaseNeuralSplineFlow, Flow
+from .distributions import Distribution, StandardNormal, Uniform, PlummerModel, BaseNeuralSplineFlow, Flow
 
 __all__ = [n for n in dir() if not n.startswith('_')]

@@ -136,6 +136,73 @@ class StandardNormal(Distribution):
         return self._sample(batch_size)
 
 
+class Uniform(Distribution):
+    """U(low, high)^dimensions as a base density (reference distributions.py:82-96, the one base its
+    BaseNeuralSplineFlow.log_prob accepts, SURVEY 2.1-5: a `tails=None` coupling stack maps into [0, 1]^D).
+    As upstream, log_prob is the constant dimensions * log(1 / (high - low)) for every row - the support is not
+    checked - and `context` is accepted and ignored.  Follows .to() / .cuda(); samples come from `generator`."""
+
+    def __init__(self, dimensions, low, high, device=None):
+        super().__init__()
+        if not float(high) > float(low):
+            raise ValueError('Uniform needs low < high')
+        self.shape = int(dimensions)
+        self.low, self.high = float(low), float(high)
+        self.params = [['Low', self.low], ['High', self.high]]
+        self.register_buffer('_anchor', torch.zeros(1, device=device), persistent=False)
+        self.generator = None
+
+    def log_prob(self, inputs, context=None):           # (no shape requirement upstream either: any [B, ...] tensor)
+        inputs = torch.as_tensor(inputs)
+        return torch.full((inputs.shape[0],), -self.shape * math.log(self.high - self.low), dtype=inputs.dtype
+                          if inputs.is_floating_point() else torch.get_default_dtype(), device=inputs.device)
+
+    def log_prob_plus(self, inputs, logabsdet, sign=1.0):
+        lp = self.log_prob(inputs)
+        return lp if logabsdet is None else lp + sign * logabsdet
+
+    def _sample(self, num_samples, context=None):
+        n = num_samples if context is None else context.shape[0] * num_samples
+        u = torch.rand(n, self.shape, device=self._anchor.device, generator=self.generator)
+        x = u * (self.high - self.low) + self.low
+        return x if context is None else x.reshape(context.shape[0], num_samples, self.shape)
+
+    def sample_n(self, batch_size, context=None):
+        return self._sample(batch_size)
+
+
+class PlummerModel(Distribution):
+    """The reference's Plummer-sphere target (distributions.py:113-144): log_prob(x) = sum over the columns of
+    log(3 / (4 pi a^3)) - 2.5 log(x^2), exactly as upstream writes it (elementwise in x, not in |x|^2 + a^2).
+    sample_n draws radii by the inverse CDF a^2 (u^(-2/3) - 1)^(-1/2) and uniform directions and returns the [B, 3]
+    points; the reference's own sample_n builds the same points and then returns `self.plummer_radius` instead
+    (distributions.py:144) - that defect is not reproduced."""
+
+    def __init__(self, plummer_radius=None, device=None):
+        super().__init__()
+        a = torch.ones(1) if plummer_radius is None else torch.as_tensor(plummer_radius, dtype=torch.get_default_dtype())
+        self.register_buffer('plummer_radius', a.to(device) if device is not None else a.clone(), persistent=False)
+        self.params = [['Radius', a.mean().item()]]
+        self.generator = None
+
+    def log_prob(self, inputs, context=None):
+        a = self.plummer_radius.to(inputs.dtype)
+        return (torch.log(3.0 / (4.0 * math.pi * a ** 3)) - 2.5 * torch.log(inputs ** 2)).sum(dim=1)
+
+    def _sample(self, num_samples, context=None):
+        if context is not None:
+            raise NotImplementedError('PlummerModel takes no context')
+        dev, a = self.plummer_radius.device, self.plummer_radius
+        u = torch.rand(3, num_samples, device=dev, generator=self.generator)
+        r = a ** 2 * (u[0] ** (-2.0 / 3.0) - 1.0) ** -0.5
+        theta, phi = 2.0 * math.pi * u[1], torch.acos(2.0 * u[2] - 1.0)
+        return torch.stack([r * torch.sin(phi) * torch.cos(theta), r * torch.sin(phi) * torch.sin(theta),
+                            r * torch.cos(phi)], dim=1)
+
+    def sample_n(self, batch_size):
+        return self._sample(batch_size)
+
+
 class BaseNeuralSplineFlow(Distribution):
     """A transform plus a base distribution (reference distributions.py:147-196)."""
 

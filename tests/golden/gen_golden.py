@@ -208,6 +208,43 @@ def gen_made():
              scale=-1.0 if scale is None else scale, **rows)
 
 
+def gen_random_mask():
+    """`random_mask=True` (made.py:134-141: hidden degrees drawn with torch.randint; feed-forward blocks only,
+    :305-306): the MADE alone and an RQ-spline transform on it, forward and the D-pass inverse.  The drawn masks and
+    degrees travel in the state_dict; `build_seed` is the torch seed the networks were constructed under, so a port
+    that draws its degrees with the same calls can be checked to build the same masks."""
+    build_seed = 77
+    torch.manual_seed(build_seed)
+    net = made.MADE(features=6, hidden_features=16, output_multiplier=23, use_residual_blocks=False,
+                    random_mask=True, num_blocks=2).eval()
+    x = torch.randn(32, 6)
+    with torch.no_grad():
+        y32 = net(x)
+        y64 = net.double()(x.double())
+    net.float()
+    save('made_small_random_mask', x=x, y32=y32, y64=y64, build_seed=build_seed, **sd_np(net.state_dict(), 'sd/'))
+
+    D, H, K, T = 6, 16, 8, 3.0
+    torch.manual_seed(build_seed + 1)
+    t = transforms.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        features=D, hidden_features=H, num_bins=K, tails='linear', tail_bound=T, num_blocks=2,
+        use_residual_blocks=False, random_mask=True).eval()
+    with torch.no_grad():
+        for prm in t.parameters():                       # default init is near-identity: make the spline do something
+            prm.mul_(3.0)
+    x = torch.randn(48, D) * 1.5
+    with torch.no_grad():
+        y32, l32 = t(x)
+        sd32 = {k: v.clone() for k, v in t.state_dict().items()}
+        with f64():
+            t.double()
+            y64, l64 = t(x.double())
+            xi64, li64 = t.inverse(y64)
+        t.float()
+    save('rqar_random_mask', x=x, y32=y32, lad32=l32, y64=y64, lad64=l64, xinv64=xi64, ladinv64=li64,
+         build_seed=build_seed + 1, features=D, hidden=H, num_bins=K, tail_bound=T, **sd_np(sd32, 'sd/'))
+
+
 def gen_activations():
     """MADE / ResidualNet built with activations other than the default ReLU (made.py:302, resnet.py:66)."""
     for name, act in [('tanh', torch.tanh), ('elu', torch.nn.functional.elu)]:
@@ -562,6 +599,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'cubic_unconditional':
         gen_cubic_unconditional()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'random_mask':
+        gen_random_mask()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'activations':
         gen_activations()
         sys.exit(0)
@@ -577,3 +617,4 @@ if __name__ == '__main__':
     gen_unconditional_coupling()
     gen_activations()
     gen_cubic_unconditional()
+    gen_random_mask()

@@ -2578,3 +2578,58 @@ def test_f16x2_256_row_tile_kernels_equal_the_128_row_kernel(nf, B, inverse):
     y32, l32 = O._rq_ar_elementwise(x.cpu(), h.cpu() @ pm.t() + b.cpu(), K, Tb, inverse, (1e-3, 1e-3, 1e-3))
     assert_close(y1, ref_y, y32)
     assert_close(l1, ref_l, l32)
+
+
+def test_random_mask_made_and_transform_golden(nf):
+    """`random_mask=True` conditioners (reference made.py:134-141) from the reference's own fixtures, drawn masks
+    included: the MADE alone; the RQ-spline transform on such a MADE, forward and inverse - its hidden units are not
+    in degree order, so the inverse takes the windowed incremental path - in the exact-fp32 and the f16x2 modes."""
+    fx = load_golden('made_small_random_mask')
+    net = nf.MADE(features=6, hidden_features=16, output_multiplier=23, use_residual_blocks=False, random_mask=True,
+                  num_blocks=2)
+    net.load_state_dict(golden_state_dict(fx), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(dev(fx['x']))
+    assert_close(y, fx['y64'], fx['y32'])
+
+    fx = load_golden('rqar_random_mask')
+    D, H, K, Tb = int(fx['features']), int(fx['hidden']), int(fx['num_bins']), float(fx['tail_bound'])
+    t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        features=D, hidden_features=H, num_bins=K, tails='linear', tail_bound=Tb, num_blocks=2,
+        use_residual_blocks=False, random_mask=True)
+    t.load_state_dict(golden_state_dict(fx), strict=True)
+    t = t.cuda().eval()
+    for mode in ('f32', 'f16x2'):
+        nf.set_matmul_dtype(mode)
+        try:
+            with torch.no_grad():
+                y, lad = t(dev(fx['x']))
+                xi, li = t.inverse(dev(fx['y64']).float())
+        finally:
+            nf.set_matmul_dtype('f32')
+        assert_close(y, fx['y64'], fx['y32'])
+        assert_close(lad, fx['lad64'], fx['lad32'])
+        # the D-pass inverse: against the reference's fp64 inverse of the same y (rounded to fp32 on the way in)
+        assert rel_err(xi.cpu(), fx['xinv64']) < 1e-4, (mode, rel_err(xi.cpu(), fx['xinv64']))
+        assert rel_err(li.cpu(), fx['ladinv64']) < 1e-4, (mode, rel_err(li.cpu(), fx['ladinv64']))
+
+
+def test_uniform_base_under_a_no_tails_coupling_stack(nf):
+    """BaseNeuralSplineFlow with the reference's own working base (distributions.py:82-96, :154-157: Uniform is the
+    one base its log_prob accepts with `context=`): a `tails=None` RQ coupling stack maps [0, 1]^D onto itself, so
+    log_prob(x) = logabsdet + D log(1 / (high - low)) = the reference's logabsdet for U(0, 1); sampling draws from the
+    base and inverts; sample_and_log_prob's density is minus that of the round trip."""
+    fx = load_golden('rq_coupling_notails')
+    comp = _coupling_stack(nf, fx, None)
+    D = int(fx['features'])
+    flow = nf.BaseNeuralSplineFlow(comp, nf.Uniform(D, 0.0, 1.0)).cuda().eval()
+    with torch.no_grad():
+        lp = flow.log_prob(dev(fx['x']))
+        assert_close(lp, fx['ld64'], fx['ld'])
+        wide = nf.BaseNeuralSplineFlow(comp, nf.Uniform(D, -1.0, 3.0)).cuda()
+        assert_close(wide.log_prob(dev(fx['x'])), fx['ld64'] - D * np.log(4.0), fx['ld'] - np.float32(D * np.log(4.0)))
+        flow._distribution.generator = torch.Generator(device='cuda').manual_seed(3)
+        s, lq = flow.sample_and_log_prob(500)
+        assert s.shape == (500, D) and s.min() >= 0 and s.max() <= 1
+        assert rel_err(flow.log_prob(s).cpu(), lq.cpu()) < 1e-3           # density of a sample = what sampling reported

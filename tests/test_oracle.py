@@ -375,3 +375,37 @@ def test_cubic_coupling_with_unconditional_transform():
     y64, ld64 = O.composite([lambda v, s=s: O.cubic_coupling(s, v, K, 'linear', Tb, Hn, unconditional=True) for s in l64],
                             T(fx['x']).double())
     assert torch.equal(y64, T(fx['y64'])) and torch.equal(ld64, T(fx['ld64']))
+
+
+def test_random_mask_made_and_transform():
+    """`random_mask=True` (reference made.py:134-141; feed-forward blocks only): fixtures written from the reference
+    with the drawn masks in their state_dict.  The oracle applies whatever masks the state_dict holds, and the
+    package's own MADE, built under the fixture's torch seed, draws the same degrees and masks as the reference's."""
+    import normalizing_flows_amd as nf
+    fx = load_golden('made_small_random_mask')
+    sd = golden_state_dict(fx)
+    assert torch.equal(O.made_forward(sd, T(fx['x'])), T(fx['y32']))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    assert rel_err(O.made_forward(sd64, T(fx['x']).double()), fx['y64']) < 1e-14
+    # the masks are not the deterministic ones
+    det = O.made_masks(6, 16, output_multiplier=23, use_residual_blocks=False)
+    assert any(not torch.equal(m, sd[name + '.mask']) for name, (m, _) in det.items())
+    torch.manual_seed(int(fx['build_seed']))
+    net = nf.MADE(features=6, hidden_features=16, output_multiplier=23, use_residual_blocks=False, random_mask=True,
+                  num_blocks=2)
+    for k, v in net.state_dict().items():
+        if k.endswith(('.mask', '.degrees')):
+            assert torch.equal(v, sd[k]), k
+    net.load_state_dict(sd, strict=True)                     # reference keys load as they are
+    with pytest.raises(ValueError):
+        nf.MADE(features=6, hidden_features=16, random_mask=True)        # residual blocks + random masks (made.py:305-306)
+
+    fx = load_golden('rqar_random_mask')
+    sd = golden_state_dict(fx)
+    K, Tb = int(fx['num_bins']), float(fx['tail_bound'])
+    y, lad = O.rq_autoregressive_forward(sd, T(fx['x']), K, Tb)
+    assert torch.equal(y, T(fx['y32'])) and torch.equal(lad, T(fx['lad32']))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    xi, li = O.rq_autoregressive_inverse(sd64, T(fx['y64']), K, Tb)
+    assert rel_err(xi, fx['xinv64']) < 1e-12 and rel_err(li, fx['ladinv64']) < 1e-12
+    assert rel_err(T(fx['xinv64']), T(fx['x']).double()) < 1e-9          # still autoregressive: the D passes invert it
