@@ -2610,9 +2610,24 @@ def test_random_mask_made_and_transform_golden(nf):
             nf.set_matmul_dtype('f32')
         assert_close(y, fx['y64'], fx['y32'])
         assert_close(lad, fx['lad64'], fx['lad32'])
-        # the D-pass inverse: against the reference's fp64 inverse of the same y (rounded to fp32 on the way in)
-        assert rel_err(xi.cpu(), fx['xinv64']) < 1e-4, (mode, rel_err(xi.cpu(), fx['xinv64']))
-        assert rel_err(li.cpu(), fx['ladinv64']) < 1e-4, (mode, rel_err(li.cpu(), fx['ladinv64']))
+        # the D-pass inverse against the reference's fp64 inverse.  The fixture's weights are 3x the default init, and
+        # the inverse of this layer is ill-conditioned: the reference's own op sequence in fp32 (the oracle, bit-equal
+        # to it on every fixture) lands 1.1e-2 from its fp64 result, fp64 arithmetic on the fp32-rounded y 3e-3 - so
+        # the bar is assert_close's floor rule, with the oracle's fp32 inverse of the same y as the floor ...
+        sd = {k: torch.as_tensor(v) for k, v in golden_state_dict(fx).items()}
+        with torch.no_grad():
+            xo, lo = O.rq_autoregressive_inverse(sd, torch.as_tensor(fx['y64']).float(), K, Tb)
+        assert_close(xi, fx['xinv64'], xo)
+        assert_close(li, fx['ladinv64'], lo)
+        # ... and, independent of the conditioning, what was returned IS an inverse: pushed forward again it gives y
+        nf.set_matmul_dtype(mode)
+        try:
+            with torch.no_grad():
+                y2, lad2 = t(xi)
+        finally:
+            nf.set_matmul_dtype('f32')
+        assert rel_err(y2.cpu(), fx['y64']) < 2e-5, (mode, rel_err(y2.cpu(), fx['y64']))
+        assert rel_err((lad2 + li).cpu(), np.zeros(len(li))) < 1e-3, (mode, (lad2 + li).abs().max().item())
 
 
 def test_uniform_base_under_a_no_tails_coupling_stack(nf):
