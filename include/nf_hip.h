@@ -212,6 +212,39 @@ int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h
                          int tails, double tail_bound, double min_bin_width, double min_bin_height,
                          double min_derivative, int inverse, int dtype, void* stream);
 
+/* ---- the MADE hidden stack in one launch (NF_DTYPE_F16X2 arithmetic) -----------------------------------
+ *      (replaces made.py:352-357 `initial_layer` + `blocks`: made.py:150-152 per layer, the residual blocks of
+ *      :268-284 or the feed-forward blocks of :196-207, ReLU, no context, no BatchNorm) ------------------
+ * A 512-thread workgroup carries 64 samples through every hidden layer: the layer input lives in LDS as two fp16
+ * term planes scaled by a power of two taken from THAT 64-row tile, the hidden state stays in fp32 accumulator
+ * registers, and only the final hidden state leaves the CU - as the tiled fp16 term planes nf_made_rqs_fwd_planes
+ * reads, with max |h| of each 64-row group in row_scale.
+ * Limits (nf_made_hidden_supported): 1..8 layers, hidden a multiple of 32 and <= 512, and no hidden unit of the
+ * first layer may read an input column >= 512 (k_live0 = 1 + the last input column with an unmasked weight;
+ * MADE's degree-ordered masks give k_live0 = hidden).
+ * types[l]: 0 = initial layer (l == 0 only), 1 / 2 = first / second linear of a residual block, 3 = feed-forward
+ * block.  W / mask / bias: host arrays of n_layers DEVICE pointers ([hidden, in_features[l]] row-major; mask or
+ * mask[l] NULL = dense; bias or bias[l] NULL = 0); in_features[l] = hidden for l > 0. */
+int nf_made_hidden_supported(int n_layers, int hidden, int k_live0);
+size_t nf_made_hidden_packed_bytes(int n_layers, int hidden, const int* in_features);
+int nf_made_hidden_pack(const float* const* W, const float* const* mask, const float* const* bias,
+                        const int* in_features, const int* types, int n_layers, int hidden, int k_live0,
+                        void* packed, void* stream);
+/* bytes of `planes` for B rows (whole 128-row tiles); row_scale holds 2 * ceil(B / 128) uint32 */
+size_t nf_made_hidden_planes_bytes(int64_t B, int hidden);
+/* x [B, in0] -> planes + row_scale (+ h_out [B, hidden] fp32 when not NULL; 16-byte aligned rows). */
+int nf_made_hidden_planes_fwd(const float* x, int64_t x_row_stride, const void* packed, int n_layers, int hidden,
+                              int in0, void* planes, uint32_t* row_scale, float* h_out, int64_t h_row_stride,
+                              int64_t B, void* stream);
+/* nf_made_rqs_fwd_hmax on the output of nf_made_hidden_planes_fwd instead of an fp32 hidden state: no max pass, no
+ * split pass (packed_w from nf_made_rqs_pack with NF_DTYPE_F16X2; workspace per nf_made_rqs_workspace_bytes + 512). */
+int nf_made_rqs_fwd_planes(const void* planes, const uint32_t* row_scale, const void* packed_w, const int32_t* ktab,
+                           const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                           int64_t y_row_stride, uint32_t* y_max, float* logabsdet, int accumulate, int32_t* bin_idx,
+                           float* workspace, size_t workspace_bytes, int64_t B, int in, int features, int K, int tails,
+                           double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                           int inverse, void* stream);
+
 /* nf_made_rqs_fwd WITHOUT a workspace argument and without any allocation.  No counterpart in the reference: it is
  * for callers that cannot allocate - code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc.  The per-tile logdet partials (for the split-operand dtypes also the hidden state's scale slot and, when

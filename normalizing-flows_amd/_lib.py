@@ -98,6 +98,19 @@ _SIGNATURES = {
                                         _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                         _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
                                         _c.c_int, _c.c_void_p]),
+    'nf_made_hidden_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
+    'nf_made_hidden_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_made_hidden_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
+                                       _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    'nf_made_hidden_planes_bytes': (_c.c_size_t, [_c.c_int64, _c.c_int]),
+    'nf_made_hidden_planes_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
+                                             _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                             _c.c_void_p]),
+    'nf_made_rqs_fwd_planes': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                          _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int,
+                                          _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int,
+                                          _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double,
+                                          _c.c_int, _c.c_void_p]),
     'nf_linear_split_tiles': (_c.c_int, [_c.c_int]),
     'nf_linear_split_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_linear_split_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int,
@@ -723,6 +736,95 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
         code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * (3 * pf.K - 1), B), launch)
         _check(code, 'nf_made_rqs_fwd')
     tag_max(out, y_max)                 # (None outside the split-operand whole-layer launches)
+    return out, logabsdet, bins
+
+
+class PackedHiddenStack:
+    """Device blob of nf_made_hidden_pack: every hidden layer of a MADE in the operand order of the one-launch hidden
+    stack kernel (f16x2)."""
+    __slots__ = ('n_layers', 'hidden', 'in0', 'blob')
+
+    def __init__(self, layers, types, k_live0):
+        """layers: [(weight, mask or None, bias or None)], types: HS_* role of each (see include/nf_hip.h)."""
+        lib = load()
+        ws = [_dev(w.detach().contiguous(), 'weight') for w, _, _ in layers]
+        ms = [None if m is None else _dev(m.detach().contiguous(), 'mask') for _, m, _ in layers]
+        bs = [None if b is None else _dev(b.detach().contiguous(), 'bias') for _, _, b in layers]
+        n = len(layers)
+        self.n_layers, self.hidden, self.in0 = n, int(ws[0].shape[0]), int(ws[0].shape[1])
+        ins = (_c.c_int * n)(*[int(w.shape[1]) for w in ws])
+        tys = (_c.c_int * n)(*[int(t) for t in types])
+        if any(int(w.shape[0]) != self.hidden for w in ws):
+            raise ValueError('every hidden layer must have %d outputs' % self.hidden)
+        nbytes = lib.nf_made_hidden_packed_bytes(n, self.hidden, ins)
+        if nbytes == 0 or not lib.nf_made_hidden_supported(n, self.hidden, int(k_live0)):
+            raise NfError(-2, 'nf_made_hidden_pack')
+        self.blob = torch.empty(nbytes, dtype=torch.uint8, device=ws[0].device)
+        wp = (_c.c_void_p * n)(*[w.data_ptr() for w in ws])
+        mp = (_c.c_void_p * n)(*[_ptr(m) for m in ms])
+        bp = (_c.c_void_p * n)(*[_ptr(b) for b in bs])
+        with torch.cuda.device(ws[0].device):
+            _check(lib.nf_made_hidden_pack(wp, mp, bp, ins, tys, n, self.hidden, int(k_live0), self.blob.data_ptr(),
+                                           _stream()), 'nf_made_hidden_pack')
+
+
+def made_hidden_supported(n_layers, hidden, k_live0):
+    return load().nf_made_hidden_supported(int(n_layers), int(hidden), int(k_live0)) == 1
+
+
+def made_hidden_planes(x, ph, want_hidden=False):
+    """x [B, in0] -> (planes, row_scale, hidden or None): the whole hidden stack in one launch (nf_made_hidden_planes_fwd);
+    planes / row_scale are what made_rqs_planes takes."""
+    lib = load()
+    _dev(x, 'inputs')
+    xp, xs = _rows(x, 'inputs')
+    B = x.shape[0]
+    if x.shape[1] != ph.in0:
+        raise ValueError('Expected %d input features, got %d' % (ph.in0, x.shape[1]))
+    planes = torch.empty(max(16, lib.nf_made_hidden_planes_bytes(B, ph.hidden)), dtype=torch.uint8, device=x.device)
+    row_scale = torch.zeros(2 * ((B + 127) // 128) + 2, dtype=torch.int32, device=x.device)
+    hid = torch.empty((B, ph.hidden), dtype=torch.float32, device=x.device) if want_hidden else None
+
+    def launch():
+        return lib.nf_made_hidden_planes_fwd(xp, xs, ph.blob.data_ptr(), ph.n_layers, ph.hidden, ph.in0,
+                                             planes.data_ptr(), row_scale.data_ptr(), _ptr(hid),
+                                             0 if hid is None else hid.stride(0), B, _stream())
+    with torch.cuda.device(x.device):
+        code = launch() if _timer is None else _timer.record(('made_hidden', ph.in0, ph.hidden, B), launch)
+        _check(code, 'nf_made_hidden_planes_fwd')
+    return planes, row_scale, hid
+
+
+def made_rqs_planes(planes, row_scale, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accumulate=False,
+                    min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, want_bins=False, workspace=None):
+    """made_rqs on the planes of made_hidden_planes (f16x2 packs only)."""
+    lib = load()
+    _dev(x, 'inputs')
+    B = x.shape[0]
+    xp, xs = _rows(x, 'inputs')
+    if pf.dtype != NF_DTYPE_F16X2 or x.shape[1] != pf.features:
+        raise ValueError('made_rqs_planes: f16x2 pack and inputs [B,%d]' % pf.features)
+    if out is None:
+        out = torch.empty_like(x)
+    yp, ys = _rows(out, 'outputs')
+    if logabsdet is None:
+        logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        accumulate = False
+    bins = torch.empty((B, pf.features), dtype=torch.int32, device=x.device) if want_bins else None
+    ws = fused_workspace(pf, B, x.device, planes=False) if workspace is None else workspace
+    y_max = torch.empty(1, dtype=torch.int32, device=x.device)
+
+    def launch():
+        return lib.nf_made_rqs_fwd_planes(planes.data_ptr(), row_scale.data_ptr(), pf.packed.data_ptr(),
+                                          pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs, yp, ys, y_max.data_ptr(),
+                                          logabsdet.data_ptr(), int(accumulate), _ptr(bins), ws.data_ptr(),
+                                          ws.numel() * 4, B, pf.inp, pf.features, pf.K, pf.tails, float(tail_bound),
+                                          float(min_bin_width), float(min_bin_height), float(min_derivative),
+                                          int(inverse), _stream())
+    with torch.cuda.device(x.device):
+        code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * (3 * pf.K - 1), B), launch)
+        _check(code, 'nf_made_rqs_fwd_planes')
+    tag_max(out, y_max)
     return out, logabsdet, bins
 
 

@@ -61,6 +61,7 @@ struct FusedArgs {
     const int32_t* feat_index;   // nullable [D]: column of x / y that holds feature f (coupling layers)
     const unsigned* wmax;    // f16x2: bit pattern of max |packed weight| before scaling (kept after the K-range table)
     const unsigned* hmax;    // f16x2: bit pattern of max |A operand| of this launch (workspace slot or the producer's)
+    int hmax_rows;           // t kernels: hmax is an array, one entry per group of 64 rows (planes from nf_made_hidden_planes_fwd)
     const float* residual;   // split hidden-layer GEMM: nullable [M, N] added to the output
     int64_t ldr;
     int N, relu_out;         // split hidden-layer GEMM: output columns, ReLU on the output
@@ -567,6 +568,9 @@ static void launch_ktab_fused(const float* mask, int out, int in, int src_rows, 
 #endif
 #ifndef NF_KO_OUT
 #define NF_KO_OUT 0
+#endif
+#ifndef NF_KO_EPI
+#define NF_KO_EPI 0
 #endif
 #ifndef NF_EPI_PRIO
 #define NF_EPI_PRIO 0
@@ -2256,13 +2260,35 @@ __global__ __launch_bounds__(256 * RT, 2) void made_rqs_f16x2_t_kernel(const Fus
 #undef T_SB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the inputs' DMA when there were fewer than two K steps)
     TSTAMP()
+#if NF_KO_EPI
+    {   // timing-only build: the K loop alone (the accumulators folded into one value that is never stored in practice)
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_ += acc[i][j][r];
+        if (s_ == 12345.678f) g.y[tid] = s_ + bv[0] + bv[1];
+        return;
+    }
+#endif
 
     // ---- epilogue: passes of 4 features x all rows; every wave hands over the columns it holds of the pass's
     //      features, then evaluates TWO (feature, 64-row group) items of one feature as one basic block ---------------
     float ws = 1.f, wi = 1.f, hs = 1.f, hi = 1.f;
     pow2_pair(*g.wmax, ws, wi);
-    pow2_pair(*g.hmax, hs, hi);
-    const float oscale = wi * hi;
+    float osc[2];                                            // per 64 rows of this wave's 128
+    if (g.hmax_rows) {
+        const int64_t grp = (m0 >> 6) + 2 * wr;
+        pow2_pair(g.hmax[grp], hs, hi);
+        osc[0] = wi * hi;
+        pow2_pair(g.hmax[grp + 1], hs, hi);
+        osc[1] = wi * hi;
+    } else {
+        pow2_pair(*g.hmax, hs, hi);
+        osc[0] = osc[1] = wi * hi;
+    }
     // items of a pass: 4 features x 2 RT row groups of 64 = 2 per wave, both of one feature
     const int fl = RT == 2 ? w >> 1 : w;                                     // wave-uniform feature slot
     const int r0 = (RT == 2 ? (w & 1) * 128 : 0) + lane, r1 = r0 + 64;       // this lane's two sample rows
@@ -2277,7 +2303,8 @@ __global__ __launch_bounds__(256 * RT, 2) void made_rqs_f16x2_t_kernel(const Fus
             if (col >= c0 && col < c1) {
                 float* tp = tile + (col - c0) * LDTR + wr * 128 + 4 * (lane >> 5);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    const float oscale = osc[i >> 1];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
@@ -2285,6 +2312,7 @@ __global__ __launch_bounds__(256 * RT, 2) void made_rqs_f16x2_t_kernel(const Fus
                         v.z = v.z * oscale + bv[j]; v.w = v.w * oscale + bv[j];
                         *reinterpret_cast<float4*>(tp + i * 32 + 8 * q) = v;
                     }
+                }
             }
         }
         __syncthreads();
@@ -2631,8 +2659,16 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
                           double min_bin_height, double min_derivative, int inverse, int dtype, int tile_begin,
                           int tile_count, int feat_limit, int reduce, const unsigned* h_max, unsigned* y_max,
                           void* stream, float* params_out = nullptr, int64_t params_row_stride = 0,
-                          double logit_div = 1.0) {
+                          double logit_div = 1.0, const void* planes_in = nullptr, const unsigned* row_scale = nullptr) {
     if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
+    if (planes_in) {
+        // the hidden state arrives as tiled fp16 term planes with one scale per 64 rows (nf_made_hidden_planes_fwd)
+        if (dtype != NF_DTYPE_F16X2) return NF_ERR_DTYPE;
+        if (!row_scale) return NF_ERR_NULL;
+        if (((uintptr_t)planes_in & 15) != 0 || feat_index || params_out) return NF_ERR_LAYOUT;
+        h = (const float*)planes_in;                 // (only so that the null / alignment checks below pass: never read)
+        h_row_stride = (in + 3) / 4 * 4;
+    }
     if (params_out && (split_terms(dtype) || inverse || feat_index ||
                        params_row_stride < (int64_t)features * (tails ? 3 * K - 1 : 3 * K + 1)))
         return NF_ERR_LAYOUT;                       // (the f32 / bf16 forward kernel of whole autoregressive layers)
@@ -2652,7 +2688,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     FusedArgs g;
     g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
-    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max; g.vec_out = 0; g.k_reverse = 0;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.hmax_rows = 0; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max; g.vec_out = 0; g.k_reverse = 0;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     g.fpt_magic = ((1u << 20) + g.fpt - 1) / g.fpt;
     g.params_out = params_out; g.ldp = params_row_stride; g.unfold = (float)(logit_div * 0.6931471805599453);
@@ -2679,6 +2715,20 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
             const size_t part = (nf_made_rqs_workspace_bytes(B, features, K, tails) + 255) / 256 * 256;
             if (workspace_bytes < part + 256) return NF_ERR_SCRATCH;      // the hidden-state scale slot
             g.hmax = h_max ? h_max : (const unsigned*)((const char*)workspace + part);
+            if (planes_in) {
+                if (tile_count != all_tiles || feat_limit != features) return NF_ERR_SHAPE;
+                if (w8_ring_bytes(g.c.P) + w8_xs_bytes(g.fpt) > 160 * 1024) return NF_ERR_SHAPE;
+                g.hp = planes_in;
+                g.hp_ld = kp16_of(in);
+                g.hmax = row_scale;
+                g.hmax_rows = 1;
+                const size_t lds8 = (size_t)w8_ring_bytes(g.c.P, 1) + w8_xs_bytes(g.fpt, 1);
+                rc = inverse ? launch_k_t<true, 1>(g, (int)grid, lds8, s) : launch_k_t<false, 1>(g, (int)grid, lds8, s);
+                if (rc != NF_OK || !reduce) return rc;
+                hipLaunchKernelGGL(rowsum_kernel, dim3(nf_ceil_div(B, 256)), dim3(256), 0, s, workspace, all_tiles, B,
+                                   logabsdet, accumulate);
+                return nf_launch_status();
+            }
             const bool pre = tile_count == all_tiles && workspace_bytes >= part + 256 + planes_bytes(B, in, dtype);
             if (pre) {
                 g.hp = (const char*)workspace + part + 256;
@@ -2737,6 +2787,22 @@ extern "C" int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const 
                           features, logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
                           tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, dtype, 0,
                           nf_made_rqs_tiles(features, K, tails), features, 1, (const unsigned*)h_max, (unsigned*)y_max, stream);
+}
+
+// nf_made_rqs_fwd on a hidden state that nf_made_hidden_planes_fwd left as tiled fp16 term planes with one scale per
+// 64 rows (NF_DTYPE_F16X2 only): no max pass, no split pass, no fp32 hidden state in HBM at all
+extern "C" int nf_made_rqs_fwd_planes(const void* planes, const uint32_t* row_scale, const void* packed_w,
+                                      const int32_t* ktab, const float* bias_packed, const float* x, int64_t x_row_stride,
+                                      float* y, int64_t y_row_stride, uint32_t* y_max, float* logabsdet, int accumulate,
+                                      int32_t* bin_idx, float* workspace, size_t workspace_bytes, int64_t B, int in,
+                                      int features, int K, int tails, double tail_bound, double min_bin_width,
+                                      double min_bin_height, double min_derivative, int inverse, void* stream) {
+    if (!planes || !row_scale) return NF_ERR_NULL;
+    return fused_fwd_impl(nullptr, 0, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr, features,
+                          logabsdet, accumulate, bin_idx, workspace, workspace_bytes, B, in, features, K, tails,
+                          tail_bound, min_bin_width, min_bin_height, min_derivative, inverse, NF_DTYPE_F16X2, 0,
+                          nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, (unsigned*)y_max, stream, nullptr,
+                          0, 1.0, planes, (const unsigned*)row_scale);
 }
 
 extern "C" int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,

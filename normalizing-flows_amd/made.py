@@ -435,6 +435,46 @@ class MADE(nn.Module):
                         relu_in=relu_in, relu_out=relu_out, out=bufs[dst], tiles=tiles)
         return bufs[last]
 
+    def hidden_planes_pack(self):
+        """Pack for the one-launch hidden stack (nf_made_hidden_planes_fwd, f16x2 arithmetic), or None when this network
+        is outside its scope: ReLU, no BatchNorm, no active dropout, residual or feed-forward blocks, hidden width a
+        multiple of 32 up to 512, and no first-layer unit reading an input column >= 512 (the degree-ordered masks
+        with hidden_features <= 512).  A context is the caller's business: the kernel has no context path."""
+        if not self.relu_only() or any(b.training and b.dropout.p > 0 for b in self.blocks):
+            return None
+        steps, _ = self.hidden_program()
+        layers = [st[0] for st in steps]
+        key = tuple((l.weight._version, l.weight.data_ptr(), None if l.bias is None else l.bias._version,
+                     l.mask._version, l.mask.data_ptr()) for l in layers) + (self.initial_layer.weight.device,)
+        cached = getattr(self, '_hidden_planes_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        pack = None
+        H = self.final_layer.in_features
+        types = []
+        ok = all(st[6] is None for st in steps) and all(l.out_features == H for l in layers)
+        for i, (layer, src, dst, res, relu_in, relu_out, bn) in enumerate(steps):
+            if i == 0:
+                types.append(0)
+                ok = ok and not relu_in and not relu_out and res is None
+            elif relu_in and not relu_out and res is None:
+                types.append(1)           # first linear of a residual block
+            elif relu_in and not relu_out and res is not None:
+                types.append(2)
+                ok = ok and types[-2] == 1 and res == steps[i - 1][1]
+            elif relu_out and not relu_in and res is None:
+                types.append(3)           # feed-forward block
+            else:
+                ok = False
+                types.append(-1)
+        if ok:
+            live = self.initial_layer.mask.ne(0).any(0).nonzero()
+            k_live0 = int(live.max().item()) + 1 if live.numel() else 1
+            if _lib.made_hidden_supported(len(layers), H, k_live0):
+                pack = _lib.PackedHiddenStack([(l.weight, l.mask, l.bias) for l in layers], types, k_live0)
+        object.__setattr__(self, '_hidden_planes_cache', (key, pack))
+        return pack
+
     def inverse_rows_pack(self, num_bins, tails, kind=None):
         """Parameter blob for the row-resident inverse kernel (nf_made_rqs_inverse_rows; num_bins None: the affine
         variant nf_made_affine_inverse_rows), or None when this

@@ -30,6 +30,8 @@ CHUNK_ROWS = 131072
 
 # False: always take the windowed incremental inverse (A/B measurements, tests of that path)
 ROW_RESIDENT_INVERSE = True
+# False: the f16x2 mode runs the hidden stack as one launch per layer (A/B measurements, tests of that path)
+FUSED_HIDDEN_STACK = True
 
 
 def _check_2d(inputs, features):
@@ -267,9 +269,19 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         if not self._fusable():
             params = net(net_inputs, context)
             return self._elementwise(inputs, params, outputs, logabsdet, inverse, want_bins=want_bins)
-        hidden = net.forward_hidden(net_inputs, context)
         made_module._require_inference(net.final_layer)
         pf = net.final_layer._packed_fused_final(net.initial_layer.in_features, self.num_bins, self.tails)
+        if FUSED_HIDDEN_STACK and made_module.get_matmul_dtype() == 'f16x2' and context is None:
+            # two launches per layer: the whole hidden stack (nf_made_hidden_planes_fwd: the hidden state leaves the CU
+            # only as the fp16 term planes the final layer reads, one scale per 64 rows), then final layer + spline
+            ph = net.hidden_planes_pack()
+            if ph is not None:
+                planes, row_scale, _ = _lib.made_hidden_planes(net_inputs, ph)
+                return _lib.made_rqs_planes(planes, row_scale, pf, inputs, self.tail_bound, inverse=inverse,
+                                            out=outputs, logabsdet=logabsdet, min_bin_width=self.min_bin_width,
+                                            min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
+                                            want_bins=want_bins)
+        hidden = net.forward_hidden(net_inputs, context)
         return _lib.made_rqs(hidden, pf, inputs, self.tail_bound, inverse=inverse, out=outputs, logabsdet=logabsdet,
                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                              min_derivative=self.min_derivative, want_bins=want_bins)
