@@ -12,6 +12,7 @@ multiple of that noise floor instead, stated in the test.
 import numpy as np
 import pytest
 import torch
+from torch.nn import functional as F
 
 from conftest import load_golden, golden_state_dict, rel_err
 from oracle import nf_oracle as O
@@ -2648,3 +2649,145 @@ def test_uniform_base_under_a_no_tails_coupling_stack(nf):
         s, lq = flow.sample_and_log_prob(500)
         assert s.shape == (500, D) and s.min() >= 0 and s.max() <= 1
         assert rel_err(flow.log_prob(s).cpu(), lq.cpu()) < 1e-3           # density of a sample = what sampling reported
+
+
+# ------------------------------------------------------------------------------- one-launch hidden stack (f16x2)
+def _decode_hidden_planes(planes, row_scale, B, H):
+    """nf_made_hidden_planes_fwd's output -> [B, H] float64: [row tile of 128][K step][term][slot = 2 row + (half ^ bit 3
+    of the row)][8 halfs], the two fp16 terms summed and the 64-row group's power-of-two scale (from max |h|) undone."""
+    steps, nt = H // 16, (B + 127) // 128
+    p = planes[:nt * steps * 2 * 256 * 16].view(torch.float16).view(nt, steps, 2, 256, 8).double()
+    v = p[:, :, 0] + p[:, :, 1]
+    rows = torch.arange(128, device=planes.device)
+    out = torch.empty(nt, 128, steps, 2, 8, dtype=torch.float64, device=planes.device)
+    for half in (0, 1):
+        out[:, :, :, half] = v[:, :, 2 * rows + (half ^ ((rows >> 3) & 1))].permute(0, 2, 1, 3)
+    mx = row_scale[:2 * nt].view(torch.float32).double()
+    ex = torch.floor(torch.log2(mx.clamp_min(1e-300))) + 1            # mx = f * 2^ex, f in [0.5, 1)
+    e = torch.where(mx > 0, 14 - ex, torch.zeros_like(ex))
+    inv = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=planes.device), -e)
+    return out.reshape(nt * 128, H)[:B] * inv[torch.arange(B, device=planes.device) // 64][:, None], mx
+
+
+def _oracle_hidden64(net, x):
+    """The hidden stack of `net` in fp64 with the reference's op sequence (made.py:150-152, :196-207, :268-284, :352-357)."""
+    sd = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in net.state_dict().items()}
+    lin = lambda n, t: F.linear(t, sd[n + '.weight'] * sd[n + '.mask'], sd[n + '.bias'])   # noqa: E731
+    h = lin('initial_layer', x.cpu().double())
+    for i, blk in enumerate(net.blocks):
+        if hasattr(blk, 'linear_layers'):
+            t = lin('blocks.%d.linear_layers.0' % i, F.relu(h))
+            h = h + lin('blocks.%d.linear_layers.1' % i, F.relu(t))
+        else:
+            h = F.relu(lin('blocks.%d.linear' % i, h))
+    return h
+
+
+@pytest.mark.parametrize('D,H,blocks,residual,random_mask,B,scale', [
+    (6, 32, 2, True, False, 48, 1.0), (20, 64, 1, False, False, 100, 1.0), (64, 128, 2, True, False, 1000, 2.0),
+    (40, 96, 3, False, True, 257, 1.5), (784, 512, 2, True, False, 333, 1.0), (600, 480, 2, True, False, 130, 1.0)])
+def test_hidden_stack_one_launch(nf, D, H, blocks, residual, random_mask, B, scale):
+    """nf_made_hidden_planes_fwd (made.py:352-357 in one launch, f16x2 arithmetic): the fp32 hidden state it can also
+    write, and the term planes + per-64-row scales it hands to the fused final layer, against the reference's op
+    sequence in fp64 - residual and feed-forward blocks, random masks (unit groups with arbitrary K ranges), ragged
+    batches (B % 64, B % 128 != 0), hidden widths that are not a power of two."""
+    from normalizing_flows_amd import _lib
+    torch.manual_seed(11)
+    net = nf.MADE(features=D, hidden_features=H, output_multiplier=2, num_blocks=blocks, use_residual_blocks=residual,
+                  random_mask=random_mask)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(scale)
+    net = net.cuda().eval()
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(5)).cuda()
+    want = _oracle_hidden64(net, x)
+    with torch.no_grad():
+        nf.set_matmul_dtype('f32')
+        ref32 = net.forward_hidden(x)                    # the exact-fp32 kernels: the floor this mode is judged against
+        nf.set_matmul_dtype('f16x2')
+        try:
+            ph = net.hidden_planes_pack()
+            assert ph is not None
+            planes, rs, hid = _lib.made_hidden_planes(x, ph, want_hidden=True)
+            # ... and the whole conditioner through it: final layer on the planes' fp32 twin
+            out = net.final_layer.fused(hid)
+        finally:
+            nf.set_matmul_dtype('f32')
+    den = want.abs().max().clamp_min(1.0)
+    floor = ((ref32.cpu().double() - want).abs().max() / den).item()
+    e_hid = ((hid.cpu().double() - want).abs().max() / den).item()
+    dec, mx = _decode_hidden_planes(planes, rs, B, H)
+    e_pl = ((dec.cpu() - want).abs().max() / den).item()
+    assert e_hid <= max(2e-6, 4 * floor), (e_hid, floor)
+    assert e_pl <= max(2e-6, 4 * floor), (e_pl, floor)
+    # the scale slot of every 64-row group holds max |h| of ITS rows
+    grp_max = torch.stack([hid[s:s + 64].abs().max() for s in range(0, B, 64)]).cpu()
+    assert torch.equal(mx[:len(grp_max)].float().cpu(), grp_max)
+    want_out = F.linear(want, (net.final_layer.weight * net.final_layer.mask).detach().cpu().double(),
+                        net.final_layer.bias.detach().cpu().double())
+    assert rel_err(out.cpu(), want_out) < 1e-5
+
+
+def test_hidden_stack_scope(nf):
+    """What the one-launch kernel does not take keeps the per-layer launches (hidden_planes_pack() is None) - and the
+    transform gives the same numbers either way: BatchNorm, an activation other than ReLU, hidden widths that are not
+    a multiple of 32 or exceed 512, a first layer that reads input columns past 512."""
+    torch.manual_seed(3)
+    mk = lambda **kw: nf.MADE(features=kw.pop('features', 10), hidden_features=kw.pop('hidden', 64),   # noqa: E731
+                              output_multiplier=2, **kw).cuda().eval()
+    nf.set_matmul_dtype('f16x2')
+    try:
+        assert mk().hidden_planes_pack() is not None
+        assert mk(use_batch_norm=True).hidden_planes_pack() is None
+        assert mk(activation=torch.tanh).hidden_planes_pack() is None
+        assert mk(hidden=48).hidden_planes_pack() is None
+        assert mk(hidden=1024, features=1100).hidden_planes_pack() is None
+        assert mk(features=700, hidden=64, random_mask=True, use_residual_blocks=False).hidden_planes_pack() is None
+        assert mk(features=700, hidden=512).hidden_planes_pack() is not None         # degree order: columns 0..511 only
+    finally:
+        nf.set_matmul_dtype('f32')
+
+
+@pytest.mark.parametrize('inverse', [False, True])
+def test_rq_ar_layer_with_and_without_the_fused_hidden_stack(nf, inverse):
+    """The f16x2 layer as two launches (hidden stack + final layer on its planes, one operand scale per 64 rows) and as
+    per-layer launches (one scale per launch) against the oracle: both within the fp32 contract, on a batch whose rows
+    differ by 1e4 in size (where the per-launch scale costs the small rows bits and the per-tile scale does not)."""
+    from normalizing_flows_amd import transforms as T
+    D, H, K, Tb, B = 96, 64, 8, 3.0, 300
+    torch.manual_seed(2)
+    t = nf.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        features=D, hidden_features=H, num_bins=K, tails='linear', tail_bound=Tb, num_blocks=2).cuda().eval()
+    with torch.no_grad():
+        for p_ in t.parameters():
+            p_.mul_(2.0)
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(9)) * 1.2
+    x[200:] *= 1e-2                                       # small rows in their own 64-row groups
+    sd = {k: v.detach().cpu() for k, v in t.state_dict().items()}
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    fn = O.rq_autoregressive_forward
+    with torch.no_grad():
+        want, lad64 = fn(sd64, x.double(), K, Tb)
+        y32, lad32 = fn(sd, x, K, Tb)
+    if inverse:                                           # one elementwise-inverse pass on the same conditioner input
+        with torch.no_grad():
+            p64 = O.made_forward(sd64, x.double(), prefix='autoregressive_net.')
+            want, lad64 = O._rq_ar_elementwise(x.double(), p64, K, Tb, True, (1e-3, 1e-3, 1e-3))
+            p32 = O.made_forward(sd, x, prefix='autoregressive_net.')
+            y32, lad32 = O._rq_ar_elementwise(x, p32, K, Tb, True, (1e-3, 1e-3, 1e-3))
+    got = {}
+    nf.set_matmul_dtype('f16x2')
+    try:
+        for fused in (True, False):
+            T.FUSED_HIDDEN_STACK = fused
+            with torch.no_grad():
+                out = torch.empty(B, D, device='cuda')
+                lad = torch.empty(B, device='cuda')
+                t._transform_rows(x.cuda(), x.cuda(), None, out, lad, inverse=inverse)
+            got[fused] = (out, lad)
+            assert_close(out, want, y32)
+            assert_close(lad, lad64, lad32)
+    finally:
+        T.FUSED_HIDDEN_STACK = True
+        nf.set_matmul_dtype('f32')
+    assert rel_err(got[True][0].cpu(), got[False][0].cpu()) < 1e-5
