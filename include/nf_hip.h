@@ -212,6 +212,31 @@ int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h
                          int tails, double tail_bound, double min_bin_width, double min_bin_height,
                          double min_derivative, int inverse, int dtype, void* stream);
 
+/* ---- one RQ-spline coupling layer in one launch ---------------------------------------------------------
+ *      (replaces transforms.py:80-106 `CouplingTransform.forward` / :108-135 `inverse` with the conditioner of
+ *      nn/resnet.py:90-100 and `_piecewise_cdf`, transforms.py:212-247: nf_resnet_hidden_fwd_copy +
+ *      nf_coupling_rqs_fwd as a single kernel) --------------------------------------------------------------
+ * A 256-thread workgroup owns 64 whole rows: rows in (coalesced), hidden stack in LDS, final Linear in chunks of
+ * 4 features (P = 23) on bf16 MFMA with three-term split operands, spline evaluation with lane = sample, whole rows
+ * out (identity columns copied, transformed columns from the spline).  The 1e-5 contract.
+ * hidden_blob: nf_resnet_blob_floats layout; w_packed (nf_coupling_final_packed_bytes) / b_packed [features * P] from
+ * nf_coupling_final_pack: the final Linear as three bf16 term planes per value in MFMA operand order (six bf16 MFMAs
+ * per product = the fp32 product to 2^-22, the NF_DTYPE_BF16X3 arithmetic), logit rows folded with log2(e) /
+ * logit_div (logit_div = sqrt(hidden) for ResidualNet, transforms.py:214-216).  in_index [n_in] / feat_index
+ * [features]: int32 columns of the identity / transformed halves.  Limits (nf_coupling_layer_supported): row_width
+ * <= 512, n_in <= 128, hidden 32 or 64, P <= 128, LDS <= 160 KB.  The pack depends on the chunk geometry the library
+ * picks for (features, K, tails): pack and launch with the same library build and environment. */
+int nf_coupling_layer_supported(int row_width, int n_in, int hidden, int features, int K, int tails);
+size_t nf_coupling_final_packed_bytes(int features, int hidden, int K, int tails);
+int nf_coupling_final_pack(const float* W, const float* bias, int features, int hidden, int K, int tails,
+                           double logit_div, void* w_packed, float* b_packed, void* stream);
+int nf_coupling_rqs_layer_fwd(const float* x, int64_t x_row_stride, float* y, int64_t y_row_stride, int row_width,
+                              const int32_t* in_index, int n_in, const int32_t* feat_index, int features,
+                              const float* hidden_blob, int hidden, int num_blocks, const void* w_packed,
+                              const float* b_packed, float* logabsdet, int accumulate, int32_t* bin_idx, int64_t B,
+                              int K, int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                              double min_derivative, int inverse, void* stream);
+
 /* ---- the MADE hidden stack in one launch (NF_DTYPE_F16X2 arithmetic) -----------------------------------
  *      (replaces made.py:352-357 `initial_layer` + `blocks`: made.py:150-152 per layer, the residual blocks of
  *      :268-284 or the feed-forward blocks of :196-207, ReLU, no context, no BatchNorm) ------------------

@@ -98,6 +98,15 @@ _SIGNATURES = {
                                         _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                         _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
                                         _c.c_int, _c.c_void_p]),
+    'nf_coupling_layer_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'nf_coupling_final_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    'nf_coupling_final_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_double,
+                                          _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    'nf_coupling_rqs_layer_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p,
+                                             _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int,
+                                             _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64,
+                                             _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double,
+                                             _c.c_int, _c.c_void_p]),
     'nf_made_hidden_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_made_hidden_packed_bytes': (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_void_p]),
     'nf_made_hidden_pack': (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
@@ -1062,6 +1071,62 @@ def made_rqs_inverse_rows(pi, z, out, hidden, workspace, tail_bound, min_bin_wid
     with torch.cuda.device(z.device):
         code = launch() if _timer is None else _timer.record(('made_rqs_inverse_rows', pi.hidden, pi.features, B), launch)
         _check(code, 'nf_made_rqs_inverse_rows')
+
+
+def coupling_layer_supported(row_width, n_in, hidden, features, num_bins, tails):
+    return tails in (None, 'linear') and load().nf_coupling_layer_supported(
+        int(row_width), int(n_in), int(hidden), int(features), int(num_bins), 1 if tails == 'linear' else 0) == 1
+
+
+class PackedCouplingFinal:
+    """Device buffers of nf_coupling_final_pack: the conditioner's final Linear with the logit rows folded."""
+    __slots__ = ('features', 'hidden', 'K', 'tails', 'w', 'b')
+
+    def __init__(self, weight, bias, features, num_bins, tails, logit_div):
+        lib = load()
+        w = _dev(weight.detach().contiguous(), 'weight')
+        b = None if bias is None else _dev(bias.detach().contiguous(), 'bias')
+        t = 1 if tails == 'linear' else 0
+        self.features, self.hidden, self.K, self.tails = int(features), int(w.shape[1]), int(num_bins), t
+        P = 3 * self.K - 1 if t else 3 * self.K + 1
+        if w.shape[0] != self.features * P:
+            raise ValueError('final layer must have %d outputs' % (self.features * P))
+        nbytes = lib.nf_coupling_final_packed_bytes(self.features, self.hidden, self.K, t)
+        if nbytes == 0:
+            raise NfError(-2, 'nf_coupling_final_pack')
+        self.w = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        self.b = torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _check(lib.nf_coupling_final_pack(w.data_ptr(), _ptr(b), self.features, self.hidden, self.K, t,
+                                              float(logit_div), self.w.data_ptr(), self.b.data_ptr(), _stream()),
+                   'nf_coupling_final_pack')
+
+
+def coupling_rqs_layer(x, in_index, feat_index, blob, hidden, num_blocks, pcf, tail_bound, inverse=False,
+                       min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, want_bins=False):
+    """One RQ-spline coupling layer in one launch (nf_coupling_rqs_layer_fwd): x [B, D] -> (y [B, D], logabsdet [B],
+    bins [B, features] or None).  in_index / feat_index: int32 identity / transformed columns."""
+    lib = load()
+    _dev(x, 'inputs')
+    _dev(in_index, 'in_index', torch.int32)
+    _dev(feat_index, 'feat_index', torch.int32)
+    xp, xs = _rows(x, 'inputs')
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    yp, ys = _rows(out, 'outputs')
+    logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
+    bins = torch.empty((B, pcf.features), dtype=torch.int32, device=x.device) if want_bins else None
+
+    def launch():
+        return lib.nf_coupling_rqs_layer_fwd(xp, xs, yp, ys, x.shape[1], in_index.data_ptr(), in_index.numel(),
+                                             feat_index.data_ptr(), pcf.features, blob.data_ptr(), hidden, num_blocks,
+                                             pcf.w.data_ptr(), pcf.b.data_ptr(), logabsdet.data_ptr(), 0, _ptr(bins), B,
+                                             pcf.K, pcf.tails, float(tail_bound), float(min_bin_width),
+                                             float(min_bin_height), float(min_derivative), int(inverse), _stream())
+    with torch.cuda.device(x.device):
+        code = launch() if _timer is None else _timer.record(('coupling_layer', in_index.numel(), pcf.features, B), launch)
+        _check(code, 'nf_coupling_rqs_layer_fwd')
+    return out, logabsdet, bins
 
 
 def resnet_hidden_supported(n_in, hidden):

@@ -32,6 +32,8 @@ CHUNK_ROWS = 131072
 ROW_RESIDENT_INVERSE = True
 # False: the f16x2 mode runs the hidden stack as one launch per layer (A/B measurements, tests of that path)
 FUSED_HIDDEN_STACK = True
+# False: RQ coupling layers run as hidden-stack launch + fused final layer launch (A/B measurements, tests of that path)
+FUSED_COUPLING_LAYER = True
 
 
 def _check_2d(inputs, features):
@@ -655,6 +657,18 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         warnings.warn('Inputs to the softmax are not scaled down: initialization might be bad.')
         return 1.0
 
+    def _packed_coupling_final(self):
+        """The conditioner's final Linear for the one-launch layer kernel (nf_coupling_final_pack), cached."""
+        fl = self.transform_net.final_layer
+        key = (fl.weight._version, fl.weight.data_ptr(), None if fl.bias is None else fl.bias._version, fl.weight.device,
+               self.num_bins, self.tails, float(self._pre_div()))
+        cached = self.__dict__.get('_coupling_final_cache')
+        if cached is None or cached[0] != key:
+            cached = (key, _lib.PackedCouplingFinal(fl.weight, fl.bias, self.num_transform_features, self.num_bins,
+                                                    self.tails, self._pre_div()))
+            self.__dict__['_coupling_final_cache'] = cached
+        return cached[1]
+
     def _fusable(self, inputs):
         """The conditioner's final Linear + the spline run as one launch (nf_coupling_rqs_fwd) when the
         conditioner is this package's ResidualNet in inference mode and the spline shape fits the kernel."""
@@ -670,6 +684,17 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
         if not inputs.is_contiguous():
             inputs = inputs.contiguous()
         net = self.transform_net
+        if (FUSED_COUPLING_LAYER and net.hidden_stack_fusable(inputs, context)
+                and _lib.coupling_layer_supported(self.features, self.num_identity_features, net.hidden_features,
+                                                  self.num_transform_features, self.num_bins, self.tails)):
+            # the whole layer in one launch (nf_coupling_rqs_layer_fwd): rows in, hidden stack + final Linear + spline
+            # in LDS, rows out - exact fp32 products whatever the matrix mode
+            outputs, logabsdet, bins = _lib.coupling_rqs_layer(
+                inputs, self._index32('identity_features'), self._feat_index(), net._hidden_blob(), net.hidden_features,
+                len(net.blocks), self._packed_coupling_final(), self.tail_bound, inverse=inverse,
+                min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                min_derivative=self.min_derivative, want_bins=want_bins)
+            return (outputs, logabsdet, bins) if want_bins else (outputs, logabsdet)
         if net.hidden_stack_fusable(inputs, context):
             # the hidden-stack launch reads the identity columns anyway: it also drops them into the output, the
             # fused launch below writes the transformed columns - every column written once, no clone of the input
