@@ -192,7 +192,8 @@ def worker_stub(args):
 def coupling_cfg2_leg(nf, dev, steps, cpu_sample):
     """BASELINE.json configs[1]: 8 x PiecewiseRationalQuadraticCouplingTransform, D = 64, alternating masks,
     ResidualNet(hidden 32, 2 blocks) conditioners, K = 8, linear tails +-3, B = 1048576, log_prob in the library's
-    default (exact fp32) matrix mode.  Reference path: transforms.py:80-106, :212-247, nn/resnet.py:90-100.
+    default matrix mode (one launch per layer, nf_coupling_rqs_layer_fwd: fp32 MFMA hidden stack, final Linear on
+    three-term bf16 MFMA - fp32-level products).  Reference path: transforms.py:80-106, :212-247, nn/resnet.py:90-100.
     HBM accounting per SURVEY 8(d): 3460 algorithmic bytes per sample per layer; spline elements = B x 32 per layer."""
     from oracle import nf_oracle as O
     Dc, HID, Kc, Lc, Bc = 64, 32, 8, 8, 1 << 20
@@ -234,9 +235,13 @@ def coupling_cfg2_leg(nf, dev, steps, cpu_sample):
                         'note': 'whole step (all launches of the 8 layers) against SURVEY 8(d)\'s 3460 B per sample '
                                 'and layer'},
            'kernel_ms': {'%s_%dx%d_rows%d' % (k[0], k[1], k[2], k[3]): round(v[1], 4) for k, v in kern.items()}}
-    fused = [k for k in kern if k[0] == 'made_rqs']
+    fused = [k for k in kern if k[0] in ('coupling_layer', 'made_rqs')]
     if fused:
+        # (coupling_layer: the whole layer in one launch - hidden stack, final Linear, spline, row copy)
         out['spline_elements_per_s_in_fused_kernel'] = fused[0][3] * (Dc // 2) / (kern[fused[0]][1] * 1e-3)
+        out['layer_kernel'] = {'name': fused[0][0], 'avg_launch_ms': kern[fused[0]][1], 'launches': kern[fused[0]][0],
+                               'hbm_bytes_per_launch': Bc * Dc * 8,
+                               'hbm_gbs': Bc * Dc * 8 / (kern[fused[0]][1] * 1e-3) / 1e9}
     if cpu_sample:
         n = min(cpu_sample, Bc)
         xc = x[:n].cpu()

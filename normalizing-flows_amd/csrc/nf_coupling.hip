@@ -163,7 +163,8 @@ __global__ __launch_bounds__(RT, NKS <= 2 ? 3 : 2) void coupling_rqs_layer_kerne
             *d = residual ? *d + acc[r] : acc[r];
         }
     };
-    fetch(0, g.blob, g.kp, g.blob + (int64_t)g.hidden * g.kp);
+    const bool init_fast = g.kp <= 16 * NKS;               // (the fragment registers cover K <= hidden)
+    if (init_fast) fetch(0, g.blob, g.kp, g.blob + (int64_t)g.hidden * g.kp);
     // folded BatchNorm scale / shift of every block layer to LDS: [2 blocks][scale, shift][hidden]
     for (int e = tid; e < g.num_blocks * 4 * hd; e += RT) {
         const int l = e / (2 * hd), o = e - l * 2 * hd;    // layer l of the blocks: its (s, t) pair sits in front of its weights
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(RT, NKS <= 2 ? 3 : 2) void coupling_rqs_layer_kerne
     const float* p = g.blob + (int64_t)hd * g.kp + hd;     // first block
     const int nb = (g.ko & 4) ? 0 : g.num_blocks;
     if (nb > 0) fetch(1, p + 2 * hd, hd, p + 2 * hd + (int64_t)hd * hd);
-    run(0, T, g.kp, nullptr, H, false);
+    if (init_fast) run(0, T, g.kp, nullptr, H, false);
+    else layer<false, false>(T, ld, g.kp, g.blob, g.blob + (int64_t)hd * g.kp, nullptr, nullptr, H, hd, wave, lane);
     __syncthreads();
     for (int b = 0; b < nb; ++b) {
         const float *Wa = p + 2 * hd, *ba = Wa + (int64_t)hd * hd;

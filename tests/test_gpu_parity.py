@@ -2791,3 +2791,54 @@ def test_rq_ar_layer_with_and_without_the_fused_hidden_stack(nf, inverse):
         T.FUSED_HIDDEN_STACK = True
         nf.set_matmul_dtype('f32')
     assert rel_err(got[True][0].cpu(), got[False][0].cpu()) < 1e-5
+
+
+# ------------------------------------------------------------------------------- one-launch coupling layer
+@pytest.mark.parametrize('D,Hn,K,tails,B', [(64, 32, 8, 'linear', 1000), (10, 32, 4, 'linear', 63), (7, 64, 10, None, 130),
+                                            (33, 64, 16, 'linear', 1), (96, 32, 8, None, 257)])
+@pytest.mark.parametrize('inverse', [False, True])
+def test_coupling_layer_one_launch(nf, D, Hn, K, tails, B, inverse):
+    """nf_coupling_rqs_layer_fwd (transforms.py:80-135 + nn/resnet.py:90-100 + :212-247 as one kernel; final Linear on
+    three-term bf16 MFMA) against the oracle in fp64 and against the two-launch route (hidden-stack kernel + fused
+    final layer on fp32 MFMA): odd / even masks with uneven halves, hidden 32 and 64, K = 4 .. 16, with and without
+    tails, batches that are not a multiple of 64, both directions, bin indices."""
+    from normalizing_flows_amd import transforms as T
+    torch.manual_seed(17)
+    mask = torch.zeros(D)
+    mask[1::2] = 1
+    if D > 8:
+        mask[:3] = 1                                       # (uneven halves, transformed columns not evenly spaced)
+    t = nf.PiecewiseRationalQuadraticCouplingTransform(
+        mask, lambda i, o: nf.ResidualNet(i, o, hidden_features=Hn, num_blocks=2), num_bins=K, tails=tails,
+        tail_bound=2.5 if tails else 1.0)
+    with torch.no_grad():
+        for p_ in t.parameters():
+            p_.mul_(2.0)
+    t = t.cuda().eval()
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, D, generator=g) * 1.3 if tails else torch.rand(B, D, generator=g)
+    sd = {k: v.detach().cpu() for k, v in t.state_dict().items()}
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    tb = 2.5 if tails else 1.0
+    with torch.no_grad():
+        want, lad64 = O.rq_coupling(sd64, x.double(), K, tails, tb, hidden_features=Hn, inverse=inverse)
+        y32, lad32 = O.rq_coupling(sd, x, K, tails, tb, hidden_features=Hn, inverse=inverse)
+        got = {}
+        for fused in (True, False):
+            T.FUSED_COUPLING_LAYER = fused
+            try:
+                got[fused] = t._run(x.cuda(), None, inverse, want_bins=True)
+            finally:
+                T.FUSED_COUPLING_LAYER = True
+    for fused in (True, False):
+        y, lad, bins = got[fused]
+        assert_close(y, want, y32)
+        assert_close(lad, lad64, lad32)
+    assert rel_err(got[True][0].cpu(), got[False][0].cpu()) < 1e-5
+    # identity columns pass through bit for bit
+    idc = t.identity_features.cpu()
+    assert torch.equal(got[True][0].cpu()[:, idc], x[:, idc])
+    # bins: the two routes may differ where x sits on a knot to within fp32 (adjacent bin), nowhere else
+    b1, b0 = got[True][2].cpu(), got[False][2].cpu()
+    diff = b1 != b0
+    assert diff.float().mean().item() < 1e-3 and ((b1 - b0).abs()[diff] <= 1).all()
