@@ -212,6 +212,24 @@ int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h
                          int tails, double tail_bound, double min_bin_width, double min_bin_height,
                          double min_derivative, int inverse, int dtype, void* stream);
 
+/* nf_made_rqs_fwd_params with the conditioner output kept as bf16 [B, features * P] (16-byte aligned, row stride in
+ * elements) and the spline backward that reads it (forward direction, no pre-divisor; gradients as bf16 like
+ * nf_rqs_bwd_max_bf16; D * P % 8 == 0).  For the bf16 training mode: everything derived from the kept parameters is
+ * rounded to bf16 by the backward GEMMs anyway; y / logabsdet of the forward come from the fp32 accumulators.  No
+ * counterpart in the reference (autograd keeps fp32 throughout). */
+int nf_made_rqs_fwd_params_bf16(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                                const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                                int64_t y_row_stride, float* logabsdet, int accumulate, float* workspace,
+                                size_t workspace_bytes, int64_t B, int in, int features, int K, int tails,
+                                double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                                int dtype, double logit_div, void* params_out_bf16, int64_t params_row_stride,
+                                void* stream);
+int nf_rqs_bwd_max_bf16p(const float* x, int64_t x_row_stride, const void* params_bf16, int64_t param_row_stride,
+                         const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet, float* grad_x,
+                         int64_t grad_x_row_stride, void* grad_params_bf16, uint32_t* grad_params_max, int64_t B, int D,
+                         int K, int tails, double tail_bound, double min_bin_width, double min_bin_height,
+                         double min_derivative, void* stream);
+
 /* ---- one RQ-spline coupling layer in one launch ---------------------------------------------------------
  *      (replaces transforms.py:80-106 `CouplingTransform.forward` / :108-135 `inverse` with the conditioner of
  *      nn/resnet.py:90-100 and `_piecewise_cdf`, transforms.py:212-247: nf_resnet_hidden_fwd_copy +

@@ -186,6 +186,15 @@ _SIGNATURES = {
                                           _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_double,
                                           _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_double, _c.c_void_p,
                                           _c.c_int64, _c.c_void_p]),
+    'nf_made_rqs_fwd_params_bf16': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                               _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                               _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                               _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_double,
+                                               _c.c_void_p, _c.c_int64, _c.c_void_p]),
+    'nf_rqs_bwd_max_bf16p': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                        _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                        _c.c_int, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_double,
+                                        _c.c_void_p]),
     'nf_made_rqs_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                    _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -591,8 +600,9 @@ def rqs_bwd(x, params, grad_y, grad_lad, num_bins, tails, tail_bound, pre_div=1.
     torch.bfloat16 tensor tagged with max |gradient| (nf_rqs_bwd_max_bf16) - for a caller that feeds them to the bf16
     backward GEMMs and nowhere else."""
     lib = load()
-    for t, n in ((x, 'inputs'), (params, 'params'), (grad_y, 'grad_y'), (grad_lad, 'grad_logabsdet')):
+    for t, n in ((x, 'inputs'), (grad_y, 'grad_y'), (grad_lad, 'grad_logabsdet')):
         _dev(t, n)
+    _dev(params, 'params', params.dtype if params.dtype == torch.bfloat16 else torch.float32)
     B, D = x.shape
     xp, xs = _rows(x, 'inputs')
     pp, ps = _rows(params, 'params')
@@ -600,6 +610,19 @@ def rqs_bwd(x, params, grad_y, grad_lad, num_bins, tails, tail_bound, pre_div=1.
     gx = torch.empty((B, D), dtype=torch.float32, device=x.device)
     gxp, gxs = _rows(gx, 'grad_x')
     gl = grad_lad.contiguous()
+    if params.dtype == torch.bfloat16:
+        # parameters kept as bf16 by made_rqs_params(keep_bf16=True): gradients come back as bf16 too
+        if not bf16_out or inverse or pre_div != 1.0:
+            raise ValueError('bf16 parameters: forward direction, bf16 gradients, no pre-divisor')
+        gparams = torch.empty(params.shape, dtype=torch.bfloat16, device=x.device)
+        slot = torch.empty(1, dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            _check(lib.nf_rqs_bwd_max_bf16p(xp, xs, pp, ps, gyp, gys, gl.data_ptr(), gxp, gxs, gparams.data_ptr(),
+                                            slot.data_ptr(), B, D, int(num_bins), 1 if tails == 'linear' else 0,
+                                            float(tail_bound), float(min_bin_width), float(min_bin_height),
+                                            float(min_derivative), _stream()), 'nf_rqs_bwd_max_bf16p')
+        tag_max(gparams, slot)
+        return gx, gparams
     if bf16_out:
         gparams = torch.empty(params.shape, dtype=torch.bfloat16, device=x.device)
         slot = torch.empty(1, dtype=torch.int32, device=x.device)
@@ -842,10 +865,12 @@ def made_rqs_keeps_params(pf):
     return pf.dtype in (NF_DTYPE_F32, NF_DTYPE_BF16)
 
 
-def made_rqs_params(h, pf, x, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, logit_div=1.0):
+def made_rqs_params(h, pf, x, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, logit_div=1.0,
+                    keep_bf16=False):
     """The training forward of a whole autoregressive RQ layer: fused final MADE layer + spline that also KEEPS the
     conditioner output (what the spline's backward recomputes from).  -> (y, logabsdet[B], params[B, features * P]).
-    `logit_div`: the value pf was packed with."""
+    `logit_div`: the value pf was packed with.  keep_bf16: params come back as torch.bfloat16
+    (nf_made_rqs_fwd_params_bf16; y / logabsdet are computed from the fp32 accumulators either way)."""
     lib = load()
     _dev(h, 'hidden')
     _dev(x, 'inputs')
@@ -858,15 +883,16 @@ def made_rqs_params(h, pf, x, tail_bound, min_bin_width=1e-3, min_bin_height=1e-
     out = torch.empty_like(x)
     yp, ys = _rows(out, 'outputs')
     logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
-    params = torch.empty((B, pf.features * P), dtype=torch.float32, device=x.device)
+    params = torch.empty((B, pf.features * P), dtype=torch.bfloat16 if keep_bf16 else torch.float32, device=x.device)
     ws = fused_workspace(pf, B, x.device, planes=False)
+    fwd = lib.nf_made_rqs_fwd_params_bf16 if keep_bf16 else lib.nf_made_rqs_fwd_params
 
     def launch():
-        return lib.nf_made_rqs_fwd_params(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs,
-                                          yp, ys, logabsdet.data_ptr(), 0, ws.data_ptr(), ws.numel() * 4, B, pf.inp,
-                                          pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
-                                          float(min_bin_height), float(min_derivative), pf.dtype, float(logit_div),
-                                          params.data_ptr(), params.stride(0), _stream())
+        return fwd(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs,
+                   yp, ys, logabsdet.data_ptr(), 0, ws.data_ptr(), ws.numel() * 4, B, pf.inp,
+                   pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
+                   float(min_bin_height), float(min_derivative), pf.dtype, float(logit_div),
+                   params.data_ptr(), params.stride(0), _stream())
     with torch.cuda.device(x.device):
         code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * P, B), launch)
         _check(code, 'nf_made_rqs_fwd_params')

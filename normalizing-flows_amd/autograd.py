@@ -98,6 +98,10 @@ def _linear_backward(layer, x, grad_y, relu_in, x_max, want_x, want_w, has_bias)
     return gx, gw, gb
 
 
+# bf16 training mode: keep the conditioner output of the fused training forward as bf16 (False: fp32, A/B and tests)
+KEEP_PARAMS_BF16 = True
+
+
 class FinalRqsFn(torch.autograd.Function):
     """Final MADE layer + RQ spline of a whole autoregressive layer, forward direction, as ONE launch that also keeps the
     conditioner output (nf_made_rqs_fwd_params): (y, logabsdet) = spline(x; hidden @ (W*mask)^T + b).  Backward: the
@@ -108,8 +112,12 @@ class FinalRqsFn(torch.autograd.Function):
     def forward(ctx, x, hidden, weight, bias, layer, cfg):
         num_bins, tails, tail_bound, mins = cfg
         pf = layer._packed_fused_final(x.shape[1], num_bins, tails)
+        # bf16 mode: the kept parameters have two readers, this node's spline backward and (through it) the two bf16 /
+        # fp16 backward GEMMs - they are kept as bf16 (KEEP_PARAMS_BF16): half the bytes stored now and read then
+        keep16 = (KEEP_PARAMS_BF16 and _bf16_mode() and _lib.bf16_gradient_path(layer.in_features, layer.out_features)
+                  and (x.shape[1] * (3 * num_bins - 1 if tails == 'linear' else 3 * num_bins + 1)) % 8 == 0)
         y, lad, params = _lib.made_rqs_params(hidden, pf, x, tail_bound, min_bin_width=mins[0], min_bin_height=mins[1],
-                                              min_derivative=mins[2])
+                                              min_derivative=mins[2], keep_bf16=keep16)
         ctx.save_for_backward(x, params, hidden)
         ctx.layer, ctx.cfg, ctx.has_bias = layer, cfg, bias is not None
         ctx.h_max = _lib.tagged_max(hidden)

@@ -80,6 +80,7 @@ struct FusedArgs {
     int group_m;             // row tiles that share a weight tile back to back (L2 reuse)
     int k_reverse;           // split GEMM: walk a tile's live K range from its end down (input-gradient launches)
     float* params_out;       // made_rqs_kernel: nullable [M, D * P], the conditioner output a training forward keeps
+    int params_bf16;         // ... as bf16 (params_out is then a __bf16 array; ldp in elements either way)
     int64_t ldp;
     float unfold;            // ... whose logit columns are multiplied by this (the pack folded log2(e) / logit_div in)
     RqsConst c;
@@ -365,14 +366,26 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
             const int col = wc * 64 + j * 32 + (lane & 31);
             if (col >= fv * P) continue;
             // this lane's rows are m0 + 4 (lane >> 5) + {0..3} + 8 {0..3} + 32 i: one base pointer, constant row offsets
-            float* pc = g.params_out + (int64_t)f0 * P + col + (m0 + 4 * (lane >> 5)) * g.ldp;
+            const int64_t po = (int64_t)f0 * P + col + (m0 + 4 * (lane >> 5)) * g.ldp;
+            if (g.params_bf16) {
+                __bf16* pc = (__bf16*)g.params_out + po;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = i * HR + (r & 3) + 8 * (r >> 2);
-                    if (whole || m0 + k + 4 * (lane >> 5) < g.M) pc[k * g.ldp] = acc[i][j][r];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = i * HR + (r & 3) + 8 * (r >> 2);
+                        if (whole || m0 + k + 4 * (lane >> 5) < g.M) pc[k * g.ldp] = (__bf16)acc[i][j][r];
+                    }
+            } else {
+                float* pc = g.params_out + po;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = i * HR + (r & 3) + 8 * (r >> 2);
+                        if (whole || m0 + k + 4 * (lane >> 5) < g.M) pc[k * g.ldp] = acc[i][j][r];
+                    }
+            }
         }
     }
 
@@ -2659,7 +2672,8 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
                           double min_bin_height, double min_derivative, int inverse, int dtype, int tile_begin,
                           int tile_count, int feat_limit, int reduce, const unsigned* h_max, unsigned* y_max,
                           void* stream, float* params_out = nullptr, int64_t params_row_stride = 0,
-                          double logit_div = 1.0, const void* planes_in = nullptr, const unsigned* row_scale = nullptr) {
+                          double logit_div = 1.0, const void* planes_in = nullptr, const unsigned* row_scale = nullptr,
+                          int params_bf16 = 0) {
     if (B < 0 || in <= 0 || features <= 0 || !fused_supported(K, tails)) return NF_ERR_SHAPE;
     if (planes_in) {
         // the hidden state arrives as tiled fp16 term planes with one scale per 64 rows (nf_made_hidden_planes_fwd)
@@ -2692,6 +2706,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     g.fpt_magic = ((1u << 20) + g.fpt - 1) / g.fpt;
     g.params_out = params_out; g.ldp = params_row_stride; g.unfold = (float)(logit_div * 0.6931471805599453);
+    g.params_bf16 = params_bf16;
     const int all_tiles = (features + g.fpt - 1) / g.fpt;
     if (tile_begin < 0 || tile_count < 0 || tile_begin + tile_count > all_tiles) return NF_ERR_SHAPE;
     if (feat_limit > features || (tile_count > 0 && feat_limit <= (tile_begin + tile_count - 1) * g.fpt)) return NF_ERR_SHAPE;
@@ -2834,6 +2849,26 @@ extern "C" int nf_made_rqs_fwd_params(const float* h, int64_t h_row_stride, cons
                           tail_bound, min_bin_width, min_bin_height, min_derivative, 0, dtype, 0,
                           nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, nullptr, stream, params_out,
                           params_row_stride, logit_div);
+}
+
+// nf_made_rqs_fwd_params that keeps the conditioner output as bf16 [B, features * P] (row stride in elements): for the
+// bf16 training mode, whose backward rounds everything derived from it to bf16 anyway - half the bytes stored here and
+// half the bytes the spline backward (nf_rqs_bwd_max_bf16p) reads.  y / logabsdet are computed from the fp32
+// accumulators as in nf_made_rqs_fwd_params.
+extern "C" int nf_made_rqs_fwd_params_bf16(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
+                                           const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
+                                           int64_t y_row_stride, float* logabsdet, int accumulate, float* workspace,
+                                           size_t workspace_bytes, int64_t B, int in, int features, int K, int tails,
+                                           double tail_bound, double min_bin_width, double min_bin_height,
+                                           double min_derivative, int dtype, double logit_div, void* params_out_bf16,
+                                           int64_t params_row_stride, void* stream) {
+    if (!params_out_bf16) return NF_ERR_NULL;
+    if (((uintptr_t)params_out_bf16 & 15) != 0) return NF_ERR_LAYOUT;
+    return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr,
+                          features, logabsdet, accumulate, nullptr, workspace, workspace_bytes, B, in, features, K, tails,
+                          tail_bound, min_bin_width, min_bin_height, min_derivative, 0, dtype, 0,
+                          nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, nullptr, stream,
+                          (float*)params_out_bf16, params_row_stride, logit_div, nullptr, nullptr, 1);
 }
 
 // ---- split-operand hidden-layer GEMM ------------------------------------------------------------------

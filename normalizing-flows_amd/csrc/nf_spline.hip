@@ -104,6 +104,51 @@ __device__ __forceinline__ void span_scalar(const SpanStage& st, int rel, int nf
     for (int f = tid; f < nfl; f += kThreads) stage[f] = st.base[rel + f];
 }
 
+// The same staging for parameters kept as bf16 (the bf16 training mode's fused forward, nf_made_rqs_fwd_params_bf16): a
+// 16-byte piece holds 8 parameters and is widened on its way into the fp32 LDS stage.  shift = parameters between
+// the 16-byte boundary below the block and the block (0..7); rel / nfl in parameters, rel % 8 == 0.
+__device__ __forceinline__ SpanStage span_stage_init16(const __bf16* params, int64_t n_params, int64_t gblk) {
+    SpanStage st;
+    const int64_t ablk = gblk & ~(int64_t)7;
+    st.vec = 1;
+    st.shift = (int)(gblk - ablk);
+    st.base = nullptr;
+    const uint64_t remain = (uint64_t)(n_params - ablk) * 2u;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(params + ablk), 0,
+                                                remain > 0xffffffffull ? 0xffffffffu : (uint32_t)remain, 0x00020000);
+    return st;
+}
+
+template <int MAXV>
+__device__ __forceinline__ void span_issue16(const SpanStage& st, int rel, int nfl, int tid, float4 (&pre)[MAXV]) {
+    const int nvec = (st.shift + nfl + 7) >> 3;
+#pragma unroll
+    for (int i = 0; i < (MAXV + 1) / 2; ++i) {
+        const int v = tid + i * kThreads;
+        const uint32_t off = v < nvec ? (uint32_t)(rel + 8 * v) * 2u : 0xfffffff0u;
+        pre[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(st.rsrc, off, 0, 0));
+    }
+}
+
+template <int MAXV>
+__device__ __forceinline__ void span_commit16(const SpanStage& st, int nfl, int tid, float* stage, const float4 (&pre)[MAXV]) {
+    const int nvec = (st.shift + nfl + 7) >> 3;
+#pragma unroll
+    for (int i = 0; i < (MAXV + 1) / 2; ++i) {
+        const int v = tid + i * kThreads;
+        if (v < nvec) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 w = __builtin_bit_cast(u4, pre[i]);                       // bf16 -> fp32: the 16 bits moved up
+            *reinterpret_cast<float4*>(stage + 8 * v) =
+                make_float4(__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u),
+                            __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u));
+            *reinterpret_cast<float4*>(stage + 8 * v + 4) =
+                make_float4(__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u),
+                            __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xffff0000u));
+        }
+    }
+}
+
 // FAM: 0 rational-quadratic, 1 linear, 2 quadratic, 3 cubic spline (nf_spline_families.h); the staging is the same
 template <int KT, bool INV, int MAXV, int FAM = 0>
 __global__ __launch_bounds__(kThreads) void rqs_kernel(const RqsArgs a) {
@@ -237,12 +282,13 @@ struct RqsBwdArgs {
     unsigned* gmax;            // nullable: atomicMax of the bit pattern of the largest finite |grad_params| written
     __bf16* gparams16;         // nullable: grad_params go HERE as bf16 [B, D*P] instead of to gparams (the bf16 training
                                // mode's backward GEMMs round them to 8 bits anyway: half the bytes written and re-read)
+    const __bf16* params16;    // PB16 kernels: the parameters as bf16 [B, D*P] (16-byte aligned; gparams16 required)
 };
 
 // FAM 0: rational-quadratic (gradients overwrite the staged parameters in place); 1 / 2 / 3: linear / quadratic /
 // cubic family (nf_spline_families.h), whose reverse sweeps keep the parameters and write a second LDS region.
 // The next span's parameters are in flight (registers) while this one is evaluated and written back.
-template <int KT, int MAXV, int FAM = 0>
+template <int KT, int MAXV, int FAM = 0, bool PB16 = false>
 __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -255,7 +301,8 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     float* gout = FAM ? smem + ((kThreads * P + 4 + 3) & ~3) : smem;
     const int64_t e0 = row0 * D;
     const int64_t gblk = e0 * P;
-    const SpanStage st = span_stage_init(a.params, a.n_param_floats, gblk, a.vec_ok);
+    const SpanStage st = PB16 ? span_stage_init16(a.params16, a.n_param_floats, gblk)
+                              : span_stage_init(a.params, a.n_param_floats, gblk, a.vec_ok);
     const bool flat = a.x_stride == D && a.gy_stride == D && a.gx_stride == D;
     const float inv_d = 1.0f / (float)D;
     float* gbase = a.gparams + (gblk - st.shift);          // 16-byte aligned when st.vec
@@ -291,16 +338,20 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
         gm = fmaxf(gm, av < INFINITY ? av : 0.0f);
     };
     float4 pre[MAXV];
-    if (st.vec && E > 0) span_issue<MAXV>(st, 0, min(kThreads, E) * P, tid, pre);
+    if (PB16) { if (E > 0) span_issue16<MAXV>(st, 0, min(kThreads, E) * P, tid, pre); }
+    else if (st.vec && E > 0) span_issue<MAXV>(st, 0, min(kThreads, E) * P, tid, pre);
     for (int it0 = 0; it0 < E; it0 += kThreads) {
         const int n = min(kThreads, E - it0);
         __syncthreads();
-        if (st.vec) span_commit<MAXV>(st, n * P, tid, stage, pre);
+        if (PB16) span_commit16<MAXV>(st, n * P, tid, stage, pre);
+        else if (st.vec) span_commit<MAXV>(st, n * P, tid, stage, pre);
         else span_scalar(st, it0 * P, n * P, tid, stage);
         __syncthreads();
         const float xv = x_ahead, gyv = gy_ahead, gl = gl_ahead;
         fetch_ahead(it0 + kThreads + tid);
-        if (st.vec && it0 + kThreads < E)
+        if (PB16) {
+            if (it0 + kThreads < E) span_issue16<MAXV>(st, (it0 + kThreads) * P, min(kThreads, E - it0 - kThreads) * P, tid, pre);
+        } else if (st.vec && it0 + kThreads < E)
             span_issue<MAXV>(st, (it0 + kThreads) * P, min(kThreads, E - it0 - kThreads) * P, tid, pre);
         if (tid < n) {
             const int e = it0 + tid;
@@ -377,6 +428,12 @@ template <int KT>
 int launch_rqs_bwd_k(const RqsBwdArgs& a, int grid, size_t lds, hipStream_t s) {
     const int nv = (kThreads * a.c.P + 4 + 3) / 4;
     const int per = (nv + kThreads - 1) / kThreads;
+    if (a.params16) {
+        if (per <= 6) { if (const int e = launch_spline<rqs_bwd_kernel<KT, 6, 0, true>>(a, grid, lds, s)) return e; }
+        else if (per <= 12) { if (const int e = launch_spline<rqs_bwd_kernel<KT, 12, 0, true>>(a, grid, lds, s)) return e; }
+        else return NF_ERR_SHAPE;
+        return nf_launch_status();
+    }
     if (per <= 6) { if (const int e = launch_spline<rqs_bwd_kernel<KT, 6>>(a, grid, lds, s)) return e; }
     else if (per <= 12) { if (const int e = launch_spline<rqs_bwd_kernel<KT, 12>>(a, grid, lds, s)) return e; }
     else if (per <= 25) { if (const int e = launch_spline<rqs_bwd_kernel<KT, 25>>(a, grid, lds, s)) return e; }
@@ -782,7 +839,7 @@ static int rqs_bwd_impl(const float* x, int64_t x_row_stride, const float* param
                         float* grad_x, int64_t grad_x_row_stride, float* grad_params, int64_t B, int D, int K,
                         int tails, double tail_bound, double min_bin_width, double min_bin_height,
                         double min_derivative, int inverse, void* stream, uint32_t* grad_params_max = nullptr,
-                        void* grad_params_bf16 = nullptr) {
+                        void* grad_params_bf16 = nullptr, const void* params_bf16 = nullptr) {
     if (B < 0 || D <= 0 || K <= 0 || K > 32) return NF_ERR_SHAPE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
     if (grad_params_max) {                                 // the slot starts at 0 even for an empty batch
@@ -790,7 +847,8 @@ static int rqs_bwd_impl(const float* x, int64_t x_row_stride, const float* param
         if (me != hipSuccess) return (int)me;
     }
     if (B == 0) return NF_OK;
-    if (!x || !params || !grad_y || !grad_logabsdet || !grad_x || (!grad_params && !grad_params_bf16)) return NF_ERR_NULL;
+    if (!x || (!params && !params_bf16) || !grad_y || !grad_logabsdet || !grad_x || (!grad_params && !grad_params_bf16)) return NF_ERR_NULL;
+    if (params_bf16 && (!grad_params_bf16 || (((uintptr_t)params_bf16 | (uintptr_t)grad_params_bf16) & 15) != 0)) return NF_ERR_LAYOUT;
     const int P = tails ? 3 * K - 1 : 3 * K + 1;
     if (param_row_stride != (int64_t)D * P) return NF_ERR_LAYOUT;
     if (x_row_stride < D || grad_y_row_stride < D || grad_x_row_stride < D) return NF_ERR_LAYOUT;
@@ -800,11 +858,12 @@ static int rqs_bwd_impl(const float* x, int64_t x_row_stride, const float* param
     a.gx_stride = grad_x_row_stride; a.gparams = grad_params; a.B = B; a.D = D;
     a.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, pre_div);
     a.rows_per_block = pick_rows_per_block(D, B);
-    a.vec_ok = (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0 && ((uintptr_t)grad_params_bf16 & 7) == 0;
+    a.vec_ok = params_bf16 ? 1 : (((uintptr_t)params | (uintptr_t)grad_params) & 15) == 0 && ((uintptr_t)grad_params_bf16 & 7) == 0;
     a.inverse = inverse;
     a.gmax = grad_params_max;
     a.gparams16 = (__bf16*)grad_params_bf16;
-    const size_t lds = sizeof(float) * (size_t)((kThreads * P + 4 + 3) & ~3);
+    a.params16 = (const __bf16*)params_bf16;
+    const size_t lds = sizeof(float) * (size_t)((kThreads * P + 8 + 7) & ~7);
     const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -854,6 +913,7 @@ static int family_bwd(const float* x, int64_t x_row_stride, const float* params,
     a.inverse = inverse;
     a.gmax = nullptr;
     a.gparams16 = nullptr;
+    a.params16 = nullptr;
     const size_t lds = 2 * sizeof(float) * (size_t)((kThreads * P + 4 + 3) & ~3);     // parameters + gradients
     if (lds > 160 * 1024) return NF_ERR_SHAPE;
     const int64_t grid = (B + a.rows_per_block - 1) / a.rows_per_block;
@@ -923,6 +983,19 @@ extern "C" int nf_rqs_bwd_max_bf16(const float* x, int64_t x_row_stride, const f
     return rqs_bwd_impl(x, x_row_stride, params, param_row_stride, pre_div, grad_y, grad_y_row_stride, grad_logabsdet,
                         grad_x, grad_x_row_stride, nullptr, B, D, K, tails, tail_bound, min_bin_width, min_bin_height,
                         min_derivative, inverse ? 1 : 0, stream, grad_params_max, grad_params_bf16);
+}
+
+// nf_rqs_bwd_max_bf16 on parameters that were KEPT as bf16 (nf_made_rqs_fwd_params_bf16): both [B, D*P] tensors of the
+// backward are 2 bytes per element (forward direction only).
+extern "C" int nf_rqs_bwd_max_bf16p(const float* x, int64_t x_row_stride, const void* params_bf16, int64_t param_row_stride,
+                                    const float* grad_y, int64_t grad_y_row_stride, const float* grad_logabsdet,
+                                    float* grad_x, int64_t grad_x_row_stride, void* grad_params_bf16,
+                                    uint32_t* grad_params_max, int64_t B, int D, int K, int tails, double tail_bound,
+                                    double min_bin_width, double min_bin_height, double min_derivative, void* stream) {
+    if (!grad_params_max || !grad_params_bf16 || !params_bf16) return NF_ERR_NULL;
+    return rqs_bwd_impl(x, x_row_stride, nullptr, param_row_stride, 1.0, grad_y, grad_y_row_stride, grad_logabsdet,
+                        grad_x, grad_x_row_stride, nullptr, B, D, K, tails, tail_bound, min_bin_width, min_bin_height,
+                        min_derivative, 0, stream, grad_params_max, grad_params_bf16, params_bf16);
 }
 
 // Backward of nf_rqs_fwd(inverse = 1): x_out = the inverse pass's OUTPUT, grad_x_out / grad_logabsdet the gradients

@@ -1857,12 +1857,13 @@ def test_bf16_gradient_plane_in_a_training_step(nf):
     flows through the input-gradient GEMM agrees to fp32 summation order (it rounds the same values to the same bf16
     operands either way); the final layers' own weight / bias gradients see 8 instead of 11 bits of each parameter
     gradient: 5e-3 of the largest entry (measured 2e-3), inside the mode's 2e-2 class."""
-    from normalizing_flows_amd import _lib
+    from normalizing_flows_amd import _lib, autograd
     D, H, K, B, Tb = 400, 512, 8, 200, 3.0
     sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=90 + j, scale=0.03) for j in range(2)]
     x = torch.randn(B, D, generator=torch.Generator().manual_seed(4)) * 1.2
     res = {}
     nf.set_matmul_dtype('bf16')
+    autograd.KEEP_PARAMS_BF16 = False                 # (the kept parameters in fp32 both times: its own test below)
     try:
         for plane in (True, False):
             _lib.BF16_GRADIENT_PLANE = plane
@@ -1874,12 +1875,59 @@ def test_bf16_gradient_plane_in_a_training_step(nf):
             res[plane] = (loss.item(), xg.grad.cpu(), {k: p.grad.cpu() for k, p in flow.named_parameters()})
     finally:
         _lib.BF16_GRADIENT_PLANE = True
+        autograd.KEEP_PARAMS_BF16 = True
         nf.set_matmul_dtype('f32')
     assert res[True][0] == res[False][0]
     assert _nerr(res[True][1], res[False][1]) < 1e-5
     for k, ref in res[False][2].items():
         bar = 5e-3 if '.final_layer.' in k else 1e-5
         assert _nerr(res[True][2][k], ref) < bar, (k, _nerr(res[True][2][k], ref))
+
+
+def test_bf16_kept_parameters_in_a_training_step(nf):
+    """bf16 mode keeps the conditioner output of the fused training forward as bf16 (nf_made_rqs_fwd_params_bf16 +
+    nf_rqs_bwd_max_bf16p; autograd.KEEP_PARAMS_BF16): the loss is bit-identical to the fp32-kept run (y and logabsdet
+    come from the fp32 accumulators).  The gradients move - the spline backward recomputes its forward quantities from
+    parameters rounded to 8 bits, and single elements change bin - but not out of the mode's class: against the fp64
+    oracle the input gradient is 10.8 % (relative l2) away with the bf16 copy and 10.5 % with the fp32 copy, i.e. the
+    bf16 GEMM that produced the parameters is the noise, not the rounding of the kept copy (the two runs differ by 7 %
+    per tensor at most).  Bars: no further from the oracle than 1.5 x the fp32-kept run, the two runs no further apart
+    than that either."""
+    from normalizing_flows_amd import autograd
+    D, H, K, B, Tb = 400, 512, 8, 200, 3.0
+    sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=90 + j, scale=0.03) for j in range(2)]
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(4)) * 1.2
+    res = {}
+    nf.set_matmul_dtype('bf16')
+    try:
+        for keep16 in (True, False):
+            autograd.KEEP_PARAMS_BF16 = keep16
+            flow = nf.BaseNeuralSplineFlow(nf.CompositeTransform(_load_layers(nf, sds, D, H, K, Tb)),
+                                           nf.StandardNormal([D])).cuda()
+            xg = x.cuda().requires_grad_(True)
+            loss = -flow.log_prob(xg).mean()
+            loss.backward()
+            res[keep16] = (loss.item(), xg.grad.cpu(), {k: p.grad.cpu() for k, p in flow.named_parameters()})
+    finally:
+        autograd.KEEP_PARAMS_BF16 = True
+        nf.set_matmul_dtype('f32')
+    assert res[True][0] == res[False][0]
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)).item()   # noqa: E731
+    worst, worst_max = l2(res[True][1], res[False][1]), _nerr(res[True][1], res[False][1])
+    for k, ref in res[False][2].items():
+        worst = max(worst, l2(res[True][2][k], ref))
+        worst_max = max(worst_max, _nerr(res[True][2][k], ref))
+    print('bf16-kept parameters: worst gradient distance to the fp32-kept run %.2e (relative l2 per tensor), %.2e of the '
+          'largest entry (single elements whose bin flips under the rounding)' % (worst, worst_max))
+    # the oracle's fp64 gradients: both runs are the bf16 mode's distance away
+    funcs = [lambda v, s_=s_: O.rq_autoregressive_forward(s_, v, K, Tb) for s_ in
+             [{k: v.double() if v.is_floating_point() else v for k, v in sd.items()} for sd in sds]]
+    x64 = x.double().requires_grad_(True)
+    (-O.flow_log_prob(funcs, x64).mean()).backward()
+    d16, d32 = l2(res[True][1], x64.grad), l2(res[False][1], x64.grad)
+    print('input gradient against the fp64 oracle: %.2e (bf16-kept), %.2e (fp32-kept)' % (d16, d32))
+    assert d16 < max(2e-2, 1.5 * d32), (d16, d32)
+    assert worst < max(2e-2, 1.5 * d32), (worst, d32)
 
 
 def test_training_gradients_in_bf16_mode(nf):
