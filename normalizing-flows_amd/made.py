@@ -37,7 +37,11 @@ def set_matmul_dtype(name):
     the hidden state by one found per launch from its largest magnitude, so any finite range is taken: the 1e-5
     contract holds for every element within 2^-14 of the launch's largest |h|; smaller ones keep 36 - log2(max/|h|)
     bits - a hidden state with a 1e6 outlier unit still gives 1e-4, tests/test_gpu_parity.py::
-    test_f16x2_with_a_heavy_tailed_hidden_state)."""
+    test_f16x2_with_a_heavy_tailed_hidden_state).  Whole-layer inference launches of the autoregressive RQ transform
+    (transforms.FUSED_HIDDEN_STACK: hidden stack + final layer as two launches) scale every group of 64 ROWS by its
+    own power of two instead - a batch whose samples differ in size by orders of magnitude costs the small ones
+    nothing there (tests/test_gpu_parity.py::test_rq_ar_layer_with_and_without_the_fused_hidden_stack); the bound above
+    then applies within a 64-row group only."""
     global _default_matmul
     if name not in _MATMUL_DTYPE:
         raise ValueError('matmul dtype must be one of %s' % sorted(_MATMUL_DTYPE))
