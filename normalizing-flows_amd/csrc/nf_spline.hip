@@ -298,7 +298,8 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     const int nrows = (int)min((int64_t)a.rows_per_block, a.B - row0);
     const int E = nrows * D;
     float* stage = smem;
-    float* gout = FAM ? smem + ((kThreads * P + 4 + 3) & ~3) : smem;
+    constexpr bool kInPlace = FAM == 0 || (FAM == 3 && KT > 0);      // the evaluator overwrites the staged parameters
+    float* gout = kInPlace ? smem : smem + ((kThreads * P + 4 + 3) & ~3);
     const int64_t e0 = row0 * D;
     const int64_t gblk = e0 * P;
     const SpanStage st = PB16 ? span_stage_init16(a.params16, a.n_param_floats, gblk)
@@ -363,7 +364,10 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
             float gxv;
             if (FAM == 1) gxv = lin_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
             else if (FAM == 2) gxv = quad_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
-            else if (FAM == 3) gxv = cubic_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
+            else if (FAM == 3) {
+                if constexpr (KT > 0) gxv = cubic_bwd_eval_t<KT>(ps, xv, gyv, gl, a.c, a.inverse != 0);
+                else gxv = cubic_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
+            }
             else gxv = rqs_bwd_eval<KT>(ps, xv, gyv, gl, a.c, a.inverse != 0);
             a.gx[gxi] = gxv;
         }
@@ -445,6 +449,14 @@ template <int FAM>
 int launch_family_bwd(const RqsBwdArgs& a, int grid, size_t lds, hipStream_t s) {
     const int nv = (kThreads * a.c.P + 4 + 3) / 4;
     const int per = (nv + kThreads - 1) / kThreads;
+    if constexpr (FAM == 3) {
+        if ((a.c.K == 8 || a.c.K == 10) && per <= 6) {            // bin count as a template constant, gradients in place
+            const size_t lds1 = lds / 2;
+            if (a.c.K == 8) hipLaunchKernelGGL((rqs_bwd_kernel<8, 6, 3>), dim3(grid), dim3(kThreads), lds1, s, a);
+            else hipLaunchKernelGGL((rqs_bwd_kernel<10, 6, 3>), dim3(grid), dim3(kThreads), lds1, s, a);
+            return nf_launch_status();
+        }
+    }
     static unsigned long long raised[3] = {0, 0, 0};
 #define NF_FAM_BWD(MAXV)                                                                              \
     do {                                                                                               \
@@ -489,6 +501,56 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(const AffineArgs a) {
     const bool flat = !a.feat && a.x_stride == D && a.y_stride == D && a.layout == NF_AFFINE_INTERLEAVED &&
                       a.p_stride == 2 * (int64_t)D;
     const int64_t e0 = row0 * D;
+    // one element: scale = sigmoid(u + 2) + 1e-3, y = scale * x + shift (or its inverse), log scale for the row sum
+    auto one = [&](float us, float shift, float xv, float& yv, float& ls) {
+        const float z = us + 2.0f;
+        const float scale = 1.0f / (1.0f + expf(-z)) + 1e-3f;
+        const float l = logf(scale);
+        yv = INV ? (xv - shift) / scale : scale * xv + shift;
+        ls = INV ? -l : l;
+    };
+    // Four consecutive elements of a row per lane and step, every access 16 bytes: no column index, D a multiple of 4,
+    // every row 16-byte addressable.  Same operations per element as the loop below (same bits).
+    // (Blocked parameters only: with interleaved ones a lane's 8 parameters are 32 bytes, two half-used 16-byte
+    // accesses per lane measured 25 % SLOWER than the flat loop below; they take two elements per lane instead - one
+    // 16-byte parameter access, 8 bytes of x and y.)
+    const bool al16 = !a.feat && !((((uintptr_t)a.x) | ((uintptr_t)a.y) | ((uintptr_t)a.params)) & 15);
+    const bool vec4 = al16 && a.layout == NF_AFFINE_BLOCKED && !(D & 3) && !((a.x_stride | a.y_stride | a.p_stride) & 3);
+    const bool vec2 = al16 && a.layout == NF_AFFINE_INTERLEAVED && !(D & 1) && !((a.x_stride | a.y_stride) & 1) &&
+                      !(a.p_stride & 3);
+    if (vec2) {
+        const int D2 = D >> 1, Q = nrows * D2;
+        const float inv_d2 = 1.0f / (float)D2;
+        for (int q = tid; q < Q; q += kThreads) {
+            const int r = div_small(q, D2, inv_d2);
+            const int d = (q - r * D2) << 1;
+            const float4 pv = *reinterpret_cast<const float4*>(a.params + (row0 + r) * a.p_stride + 2 * d);
+            const float2 xv = *reinterpret_cast<const float2*>(a.x + (row0 + r) * a.x_stride + d);
+            float2 yv, ls;
+            one(pv.x, pv.y, xv.x, yv.x, ls.x);
+            one(pv.z, pv.w, xv.y, yv.y, ls.y);
+            *reinterpret_cast<float2*>(a.y + (row0 + r) * a.y_stride + d) = yv;
+            *reinterpret_cast<float2*>(smem + r * D + d) = ls;
+        }
+    } else if (vec4) {
+        const int D4 = D >> 2, Q = nrows * D4;
+        const float inv_d4 = 1.0f / (float)D4;
+        for (int q = tid; q < Q; q += kThreads) {
+            const int r = div_small(q, D4, inv_d4);
+            const int d = (q - r * D4) << 2;
+            const float* prow = a.params + (row0 + r) * a.p_stride;
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + (row0 + r) * a.x_stride + d);
+            const float4 sh = *reinterpret_cast<const float4*>(prow + d);
+            const float4 us = *reinterpret_cast<const float4*>(prow + D + d);
+            float4 yv, ls;
+            one(us.x, sh.x, xv.x, yv.x, ls.x);
+            one(us.y, sh.y, xv.y, yv.y, ls.y);
+            one(us.z, sh.z, xv.z, yv.z, ls.z);
+            one(us.w, sh.w, xv.w, yv.w, ls.w);
+            *reinterpret_cast<float4*>(a.y + (row0 + r) * a.y_stride + d) = yv;
+            *reinterpret_cast<float4*>(smem + r * D + d) = ls;
+        }
+    } else
     for (int e = tid; e < E; e += kThreads) {
         float us, shift;
         int64_t xi, yi;
@@ -513,12 +575,10 @@ __global__ __launch_bounds__(kThreads) void affine_kernel(const AffineArgs a) {
             xi = (row0 + r) * a.x_stride + col;
             yi = (row0 + r) * a.y_stride + col;
         }
-        const float z = us + 2.0f;
-        const float scale = 1.0f / (1.0f + expf(-z)) + 1e-3f;       // sigmoid(u + 2) + 1e-3
-        const float ls = logf(scale);
-        const float xv = a.x[xi];
-        a.y[yi] = INV ? (xv - shift) / scale : scale * xv + shift;
-        smem[e] = INV ? -ls : ls;
+        float yv, ls;
+        one(us, shift, a.x[xi], yv, ls);
+        a.y[yi] = yv;
+        smem[e] = ls;
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;

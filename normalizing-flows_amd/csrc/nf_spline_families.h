@@ -726,3 +726,158 @@ __device__ __forceinline__ float cubic_bwd_eval(float* p, float* g, float x, flo
     g[2 * K + 1] = g_ur;
     return ret;
 }
+
+// The same reverse sweep with the bin count as a template constant: the element's 2 KT + 2 parameters move to registers
+// once (every index below is static after unrolling; the runtime-K version above re-reads its cached widths / heights
+// from LDS in every loop, 2-way bank conflicts at the even stride P = 2K + 2), quotients by one refined reciprocal per
+// denominator (nf_div_ieee: the bits of `/` in the normal range), the bin's neighbours picked by the search loop, and
+// the gradients written over the parameters IN PLACE - no second LDS region.  Same formulas in the same order.
+template <int KT>
+__device__ __forceinline__ float cubic_bwd_eval_t(float* p, float x, float gy, float gl, const RqsConst& a, bool inv) {
+    constexpr int K = KT, P = 2 * KT + 2;
+    typedef __attribute__((address_space(3))) float* lds_w;
+    lds_w pl = (lds_w)p;
+    if (a.tails && !(x >= a.left && x <= a.right)) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) pl[k] = 0.0f;
+        return gy;
+    }
+    float wv[K], hv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { wv[k] = pl[k]; hv[k] = pl[K + k]; }
+    const float ul = pl[2 * K], ur = pl[2 * K + 1];
+    const NfDivisor dpre = nf_divisor(a.pre_div);
+    if (a.pre_div != 1.0f) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { wv[k] = nf_div_ieee(wv[k], dpre); hv[k] = nf_div_ieee(hv[k], dpre); }
+    }
+    const float t = nf_div_ieee(x - a.left, nf_divisor(a.span));
+    float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { mw = fmaxf(mw, wv[k]); mh = fmaxf(mh, hv[k]); }
+    float sw = 0.0f, sh_ = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        wv[k] = nf_exp(wv[k] - mw);
+        hv[k] = nf_exp(hv[k] - mh);
+        sw += wv[k];
+        sh_ += hv[k];
+    }
+    const NfDivisor dsw = nf_divisor(sw), dsh = nf_divisor(sh_);
+    float smw[K], smh[K];                                  // the two softmaxes; widths / heights = min + scale * softmax
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        smw[k] = nf_div_ieee(wv[k], dsw);
+        smh[k] = nf_div_ieee(hv[k], dsh);
+        wv[k] = a.min_w + a.scale_w * smw[k];
+        hv[k] = a.min_h + a.scale_h * smh[k];
+    }
+    double accw = 0.0;
+    float cw0 = 0.0f, lw = 0.0f;
+    int b = 0;
+    float wb = 1.0f, hb = 1.0f, w0 = 1.0f, h0 = 1.0f, w1 = 1.0f, h1 = 1.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        accw += (double)wv[k];
+        if (t >= cw0) {
+            b = k; lw = cw0; wb = wv[k]; hb = hv[k];
+            if (k > 0) { w0 = wv[k - 1]; h0 = hv[k - 1]; }
+            if (k < K - 1) { w1 = wv[k + 1]; h1 = hv[k + 1]; }
+        }
+        cw0 = (float)accw;
+    }
+    const NfDivisor dwb = nf_divisor(wb), dw0 = nf_divisor(w0), dw1 = nf_divisor(w1);
+    const float sb = nf_div_ieee(hb, dwb), s0 = nf_div_ieee(h0, dw0), s1 = nf_div_ieee(h1, dw1);
+    const bool first = b == 0, last = b == K - 1;
+    // one sigmoid serves whichever end bin the element sits in (K >= 2: never both)
+    const float ue = first ? ul : ur;
+    const float sig = nf_div_ieee(1.0f, nf_divisor(1.0f + nf_exp(-ue)));
+    const NfDivisor dl01 = nf_divisor(w0 + wb), dr01 = nf_divisor(wb + w1);
+    const float m2l = nf_div_ieee(0.5f * (wb * s0 + w0 * sb), dl01);
+    const float m2r = nf_div_ieee(0.5f * (w1 * sb + wb * s1), dr01);
+    const float dl = first ? sig * 3.0f * sb : 2.0f * fminf(fminf(s0, sb), m2l);
+    const float dr = last ? sig * 3.0f * sb : 2.0f * fminf(fminf(sb, s1), m2r);
+    const float iw = dwb.r, iw2 = iw * iw;
+    const float ca = nf_div_ieee(dl + dr - 2.0f * sb, nf_divisor(wb * wb));
+    const float cb = nf_div_ieee(3.0f * sb - 2.0f * dl - dr, dwb);
+    const float cc = dl;
+    const float s = t - lw;
+    const float Dv = 3.0f * ca * (s * s) + 2.0f * cb * s + cc;
+    const float D2 = 6.0f * ca * s + 2.0f * cb;
+    const NfDivisor dDv = nf_divisor(Dv);
+    const float glv = nf_div_ieee(gl, dDv);                // gl / f'
+    float g_ca, g_cb, g_cc, g_d, g_lw, ret;
+    if (!inv) {
+        const float go = gy * a.span;
+        const float gs = go * Dv + glv * D2;
+        ret = nf_div_ieee(gs, nf_divisor(a.span));
+        g_lw = -gs;
+        g_ca = go * (s * s * s) + glv * 3.0f * (s * s);
+        g_cb = go * (s * s) + glv * 2.0f * s;
+        g_cc = go * s + glv;
+        g_d = go;
+    } else {
+        const bool quad = fabsf(ca) < 1e-3f;
+        const float Gp = quad ? 2.0f * cb * s + cc : Dv;
+        const float s3 = quad ? 0.0f : s * s * s;
+        const float gon = gy * a.span;
+        const float gs = gon - glv * D2;
+        const float q = nf_div_ieee(gs, nf_divisor(Gp));
+        ret = nf_div_ieee(q, nf_divisor(a.span));
+        g_lw = gon;
+        g_ca = -glv * 3.0f * (s * s) - q * s3;
+        g_cb = -glv * 2.0f * s - q * (s * s);
+        g_cc = -glv - q * s;
+        g_d = -q;
+    }
+    const float g_dl = g_ca * iw2 - 2.0f * g_cb * iw + g_cc;
+    const float g_dr = g_ca * iw2 - g_cb * iw;
+    float g_sb = -2.0f * g_ca * iw2 + 3.0f * g_cb * iw;
+    float g_wb = -2.0f * ca * g_ca * iw - cb * g_cb * iw;
+    float g_w0 = 0.0f, g_w1 = 0.0f, g_s0 = 0.0f, g_s1 = 0.0f, g_ul = 0.0f, g_ur = 0.0f;
+    {
+        const float gm = 2.0f * g_dl;
+        const bool edge = fminf(s0, sb) <= m2l;            // the min picked a slope, not the weighted mean
+        const float id = dl01.r;
+        g_ul = first ? g_dl * 3.0f * sb * sig * (1.0f - sig) : 0.0f;
+        g_sb += first ? g_dl * 3.0f * sig : (edge ? (s0 <= sb ? 0.0f : gm) : gm * 0.5f * w0 * id);
+        g_s0 += first ? 0.0f : (edge ? (s0 <= sb ? gm : 0.0f) : gm * 0.5f * wb * id);
+        g_wb += first || edge ? 0.0f : gm * (0.5f * s0 - m2l) * id;
+        g_w0 += first || edge ? 0.0f : gm * (0.5f * sb - m2l) * id;
+    }
+    {
+        const float gm = 2.0f * g_dr;
+        const bool edge = fminf(sb, s1) <= m2r;
+        const float id = dr01.r;
+        g_ur = last ? g_dr * 3.0f * sb * sig * (1.0f - sig) : 0.0f;
+        g_sb += last ? g_dr * 3.0f * sig : (edge ? (sb <= s1 ? gm : 0.0f) : gm * 0.5f * w1 * id);
+        g_s1 += last ? 0.0f : (edge ? (sb <= s1 ? 0.0f : gm) : gm * 0.5f * wb * id);
+        g_wb += last || edge ? 0.0f : gm * (0.5f * s1 - m2r) * id;
+        g_w1 += last || edge ? 0.0f : gm * (0.5f * sb - m2r) * id;
+    }
+    const float g_hb = g_sb * iw;
+    g_wb += -g_sb * sb * iw;
+    const float g_h0 = first ? 0.0f : g_s0 * dw0.r, g_h1 = last ? 0.0f : g_s1 * dw1.r;
+    g_w0 += first ? 0.0f : -g_s0 * s0 * dw0.r;
+    g_w1 += last ? 0.0f : -g_s1 * s1 * dw1.r;
+    // back through min + scale * softmax(u / pre_div) of the widths and of the heights
+    float gwv[K], ghv[K];
+    float Sw = 0.0f, Sh = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        gwv[k] = a.scale_w * ((k < b ? g_lw : 0.0f) + (k == b - 1 ? g_w0 : 0.0f) + (k == b ? g_wb : 0.0f) + (k == b + 1 ? g_w1 : 0.0f));
+        ghv[k] = a.scale_h * ((k < b ? g_d : 0.0f) + (k == b - 1 ? g_h0 : 0.0f) + (k == b ? g_hb : 0.0f) + (k == b + 1 ? g_h1 : 0.0f));
+        Sw += gwv[k] * smw[k];
+        Sh += ghv[k] * smh[k];
+    }
+    const float ipd = dpre.r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        pl[k] = smw[k] * (gwv[k] - Sw) * ipd;
+        pl[K + k] = smh[k] * (ghv[k] - Sh) * ipd;
+    }
+    pl[2 * K] = g_ul;
+    pl[2 * K + 1] = g_ur;
+    return ret;
+}
+
