@@ -478,8 +478,25 @@ def masked_linear_bwd_input(grad_y, plt, gate=None):
     return gx
 
 
-def masked_linear_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True):
-    """Returns (grad_w [out,in], grad_b [out] or None), freshly zeroed then accumulated by the kernel."""
+def _wgrad_out(out, inp, want_bias, device, into):
+    """(grad_w, grad_b) the weight-gradient kernels ACCUMULATE into: fresh zeros, or `into` = the caller's own
+    (grad_w, grad_b or None) - e.g. the parameters' .grad views, already holding earlier contributions."""
+    if into is None:
+        gw = torch.zeros((out, inp), dtype=torch.float32, device=device)
+        gb = torch.zeros(out, dtype=torch.float32, device=device) if want_bias else None
+        return gw, gb
+    gw, gb = into
+    for t, shape, name in ((gw, (out, inp), 'grad_w'), (gb, (out,), 'grad_b')):
+        if t is None and name == 'grad_b' and not want_bias:
+            continue
+        if t is None or t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != device:
+            raise ValueError('%s to accumulate into: a contiguous float32 tensor of shape %s on %s' % (name, shape, device))
+    return gw, (gb if want_bias else None)
+
+
+def masked_linear_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True, into=None):
+    """Returns (grad_w [out,in], grad_b [out] or None), freshly zeroed then accumulated by the kernel (`into`: the
+    caller's own pair instead, see _wgrad_out)."""
     lib = load()
     _dev(x, 'x')
     _dev(grad_y, 'grad_y')
@@ -487,8 +504,7 @@ def masked_linear_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True):
     gp, gs = _rows(grad_y, 'grad_y')
     B, inp = x.shape
     out = grad_y.shape[1]
-    gw = torch.zeros((out, inp), dtype=torch.float32, device=x.device)
-    gb = torch.zeros(out, dtype=torch.float32, device=x.device) if want_bias else None
+    gw, gb = _wgrad_out(out, inp, want_bias, x.device, into)
     m = None if mask is None else _dev(mask.contiguous(), 'mask')
     with torch.cuda.device(x.device):
         _check(lib.nf_masked_linear_bwd_weight(xp, xs, gp, gs, _ptr(m), _ptr(ktab), gw.data_ptr(), _ptr(gb), B, inp, out,
@@ -497,7 +513,7 @@ def masked_linear_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True):
 
 
 def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=True, x_max=None, grad_y_max=None,
-                                   terms=2):
+                                   terms=2, into=None):
     """masked_linear_bwd_weight on two-term fp16 operands (the f16x2 training mode) or, terms=1, on one scaled fp16
     term (the bf16 training mode: nf_masked_linear_half_bwd_weight); the max slots are computed here when the caller
     has none."""
@@ -512,8 +528,7 @@ def masked_linear_split_bwd_weight(x, grad_y, mask, ktab, relu_in, want_bias=Tru
         raise ValueError('x and grad_y disagree on the batch size')
     x_max = maxabs(x) if x_max is None else x_max
     grad_y_max = maxabs(grad_y) if grad_y_max is None else grad_y_max
-    gw = torch.zeros((out, inp), dtype=torch.float32, device=x.device)
-    gb = torch.zeros(out, dtype=torch.float32, device=x.device) if want_bias else None
+    gw, gb = _wgrad_out(out, inp, want_bias, x.device, into)
     m = None if mask is None else _dev(mask.contiguous(), 'mask')
     with torch.cuda.device(x.device):
         # wide layers: act(x) as fp16 plane(s) in a workspace (the operand every workgroup re-reads, fetched by LDS-DMA)
@@ -569,7 +584,8 @@ def masked_linear_split_bwd_input_bf16(grad_y16, pls, gate=None):
     return gx
 
 
-def masked_linear_half_bwd_weight_bf16(x, grad_y16, mask, ktab, relu_in, want_bias=True, x_max=None, grad_y_max=None):
+def masked_linear_half_bwd_weight_bf16(x, grad_y16, mask, ktab, relu_in, want_bias=True, x_max=None, grad_y_max=None,
+                                       into=None):
     """The one-term weight gradient with grad_y a torch.bfloat16 matrix (its max slot is required: the bf16 tensor's tag)."""
     lib = load()
     _dev(x, 'x')
@@ -582,8 +598,7 @@ def masked_linear_half_bwd_weight_bf16(x, grad_y16, mask, ktab, relu_in, want_bi
     out = grad_y16.shape[1]
     m = None if mask is None else _dev(mask.detach().contiguous(), 'mask')
     x_max = maxabs(x) if x_max is None else x_max
-    gw = torch.zeros((out, inp), dtype=torch.float32, device=x.device)
-    gb = torch.zeros(out, dtype=torch.float32, device=x.device) if want_bias else None
+    gw, gb = _wgrad_out(out, inp, want_bias, x.device, into)
     ws = torch.empty(B * inp * 2, dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib.nf_masked_linear_half_bwd_weight_bf16(xp, xs, x_max.data_ptr(), grad_y16.data_ptr(), grad_y16.stride(0),

@@ -11,6 +11,7 @@ model.py:233-244).  Here every forward kernel has a hand-written backward kernel
                    implicitly at its output (nf_rqs_inverse_bwd)
   AffineFn       : (y, logabsdet) = sigmoid-scale affine(x; params), either direction, AR or coupling layout
                    backward: recompute-from-inputs kernel nf_rqs_bwd -> grad_x, grad_params
+  StdNormalLogProbFn : log N(z; 0, I) + sign * logabsdet, one launch (nf_std_normal_log_prob)
   FinalRqsFn     : final MADE layer + RQ spline of a whole autoregressive layer as ONE node (f32 / bf16 modes): forward
                    nf_made_rqs_fwd_params (the parameters kept, not re-read between GEMM and spline); backward
                    nf_rqs_bwd_max + the final layer's two GEMMs - in bf16 mode with the parameter gradients as a bf16
@@ -39,6 +40,60 @@ def _bf16_mode():
     return made.get_matmul_dtype() == 'bf16'
 
 
+def _grad_sink(weight, bias, has_bias):
+    """The pair (weight.grad, bias.grad) when this node may accumulate its weight gradient straight into them, else
+    None.  parallel.GradientSynchronizer opts its parameters in (`_nf_grad_sink`): their .grad are persistent zeroed
+    views of the flat buckets, so the weight-gradient kernels - which accumulate into their output - need neither a
+    zero-filled temporary nor AccumulateGrad's add pass (4 small launches per layer and step, a 37 MB add for the final
+    layer).  The node then returns None for these inputs; the parameters' post-accumulate hooks (the synchronizer's bucket
+    countdown) still run once per backward: by the engine where it runs them for a None gradient, else by _sink_done."""
+    def ok(p):
+        g = getattr(p, 'grad', None)
+        return (getattr(p, '_nf_grad_sink', False) and p.is_leaf and p.requires_grad and g is not None
+                and g.dtype == torch.float32 and g.shape == p.shape and g.is_contiguous() and g.device == p.device
+                and g.data_ptr() % 16 == 0 and not g.requires_grad and not p._backward_hooks)
+    if not ok(weight) or (has_bias and not ok(bias)):
+        return None
+    return weight.grad, (bias.grad if has_bias else None)
+
+
+_engine_fires_hooks = None
+
+
+def _engine_fires_post_accumulate_hooks_without_a_gradient():
+    """Does this torch run a leaf's post-accumulate-grad hooks when the node feeding it returned None?  (2.10 does;
+    probed once on a 3-element CPU graph rather than assumed.)"""
+    global _engine_fires_hooks
+    if _engine_fires_hooks is None:
+        class Probe(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                return x * 1.0
+
+            @staticmethod
+            def backward(ctx, g):
+                return g, None
+        w = torch.zeros(1, requires_grad=True)
+        fired = []
+        handle = w.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+        with torch.enable_grad():
+            Probe.apply(torch.zeros(1, requires_grad=True), w).sum().backward()
+        handle.remove()
+        _engine_fires_hooks = bool(fired)
+    return _engine_fires_hooks
+
+
+def _sink_done(*params):
+    """The parameters' post-accumulate-grad hooks after a direct accumulation - unless the engine runs them anyway."""
+    if _engine_fires_post_accumulate_hooks_without_a_gradient():
+        return
+    for p in params:
+        hooks = getattr(p, '_post_accumulate_grad_hooks', None) if p is not None else None
+        if hooks:
+            for h in list(hooks.values()):
+                h(p)
+
+
 class MaskedLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, layer, relu_in):
@@ -56,20 +111,27 @@ class MaskedLinearFn(torch.autograd.Function):
         ctx.relu_in = relu_in
         ctx.has_residual = residual is not None
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
         (x,) = ctx.saved_tensors
         grad_y = grad_y.contiguous()
-        gx, gw, gb = _linear_backward(ctx.layer, x, grad_y, ctx.relu_in, ctx.x_max, ctx.needs_input_grad[0],
-                                      ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]), ctx.has_bias)
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        sink = _grad_sink(*ctx.params, ctx.has_bias) if want_w else None
+        gx, gw, gb = _linear_backward(ctx.layer, x, grad_y, ctx.relu_in, ctx.x_max, ctx.needs_input_grad[0], want_w,
+                                      ctx.has_bias, into=sink)
         gres = grad_y if ctx.has_residual else None
+        if sink is not None:
+            _sink_done(*ctx.params)
+            gw = gb = None
         return gx, gw, gb, gres, None, None
 
 
-def _linear_backward(layer, x, grad_y, relu_in, x_max, want_x, want_w, has_bias):
-    """(grad_x, grad_W, grad_b) of y = act_in(x) @ (W*mask)^T + b from grad_y, in the current matrix mode."""
+def _linear_backward(layer, x, grad_y, relu_in, x_max, want_x, want_w, has_bias, into=None):
+    """(grad_x, grad_W, grad_b) of y = act_in(x) @ (W*mask)^T + b from grad_y, in the current matrix mode (`into`: the
+    pair the weight gradient is accumulated into instead of fresh tensors, _grad_sink)."""
     gx = gw = gb = None
     split_y = _split_mode(grad_y, layer.out_features)
     gy_max = _lib.tagged_max(grad_y)                   # left by the kernel that produced it (nf_rqs_bwd_max)
@@ -87,14 +149,14 @@ def _linear_backward(layer, x, grad_y, relu_in, x_max, want_x, want_w, has_bias)
             # bf16 mode: one scaled fp16 term per operand (11 bits against bf16's 8, same MFMA rate)
             gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
                                                          layer._wgrad_ktab(), relu_in, want_bias=has_bias,
-                                                         x_max=x_max, grad_y_max=gy_max, terms=1)
+                                                         x_max=x_max, grad_y_max=gy_max, terms=1, into=into)
         elif split_y and x_max is not None and _f16x2_mode():
             gw, gb = _lib.masked_linear_split_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
                                                          layer._wgrad_ktab(), relu_in,
-                                                         want_bias=has_bias, x_max=x_max, grad_y_max=gy_max)
+                                                         want_bias=has_bias, x_max=x_max, grad_y_max=gy_max, into=into)
         else:
             gw, gb = _lib.masked_linear_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
-                                                   layer._wgrad_ktab(), relu_in, want_bias=has_bias)
+                                                   layer._wgrad_ktab(), relu_in, want_bias=has_bias, into=into)
     return gx, gw, gb
 
 
@@ -121,6 +183,7 @@ class FinalRqsFn(torch.autograd.Function):
         ctx.save_for_backward(x, params, hidden)
         ctx.layer, ctx.cfg, ctx.has_bias = layer, cfg, bias is not None
         ctx.h_max = _lib.tagged_max(hidden)
+        ctx.params = (weight, bias)
         return y, lad
 
     @staticmethod
@@ -135,6 +198,8 @@ class FinalRqsFn(torch.autograd.Function):
         h_max = ctx.h_max
         if h_max is None and _bf16_mode():
             h_max = _lib.maxabs(hidden)
+        want_w = ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3])
+        sink = _grad_sink(*ctx.params, ctx.has_bias) if want_w else None
         if _bf16_mode() and _lib.bf16_gradient_path(layer.in_features, layer.out_features):
             # bf16 mode: the parameter gradients never leave this node and both GEMMs below round them to bf16 (the
             # weight gradient: to fp16) anyway - the spline backward writes them as bf16 (half the bytes written and
@@ -145,18 +210,42 @@ class FinalRqsFn(torch.autograd.Function):
             gh = gw = gb = None
             if ctx.needs_input_grad[1]:
                 gh = _lib.masked_linear_split_bwd_input_bf16(gp16, layer._packed_linear_split_t())
-            if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            if want_w:
                 gw, gb = _lib.masked_linear_half_bwd_weight_bf16(hidden, gp16, getattr(layer, 'mask', None),
                                                                  layer._wgrad_ktab(), False, want_bias=ctx.has_bias,
-                                                                 x_max=h_max, grad_y_max=_lib.tagged_max(gp16))
+                                                                 x_max=h_max, grad_y_max=_lib.tagged_max(gp16), into=sink)
+            if sink is not None:
+                _sink_done(*ctx.params)
+                gw = gb = None
             return gx, gh, gw, gb, None, None
         gx, gparams = _lib.rqs_bwd(x, params, grad_y.contiguous(), grad_lad.contiguous(), num_bins, tails, tail_bound,
                                    min_bin_width=mins[0], min_bin_height=mins[1], min_derivative=mins[2],
                                    want_max=_f16x2_mode() or _bf16_mode())
-        gh, gw, gb = _linear_backward(ctx.layer, hidden, gparams, False, h_max, ctx.needs_input_grad[1],
-                                      ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]),
-                                      ctx.has_bias)
+        gh, gw, gb = _linear_backward(ctx.layer, hidden, gparams, False, h_max, ctx.needs_input_grad[1], want_w,
+                                      ctx.has_bias, into=sink)
+        if sink is not None:
+            _sink_done(*ctx.params)
+            gw = gb = None
         return gx, gh, gw, gb, None, None
+
+
+class StdNormalLogProbFn(torch.autograd.Function):
+    """log N(z; 0, I) + sign * logabsdet per row as one launch under autograd as well (nf_std_normal_log_prob; the
+    reference's pow / mul / add / sum / add chain and its five backward nodes otherwise: distributions.py:27-36 there).
+    Backward: d/dz = -z * g per row, d/dlogabsdet = sign * g."""
+
+    @staticmethod
+    def forward(ctx, z, logabsdet, sign):
+        ctx.save_for_backward(z)
+        ctx.sign, ctx.has_lad = float(sign), logabsdet is not None
+        return _lib.std_normal_log_prob(z, logabsdet, sign)
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        gz = z * (-g).unsqueeze(1) if ctx.needs_input_grad[0] else None
+        gl = g * ctx.sign if ctx.has_lad and ctx.needs_input_grad[1] else None
+        return gz, gl, None
 
 
 class RqsFn(torch.autograd.Function):

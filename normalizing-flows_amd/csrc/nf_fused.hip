@@ -2893,8 +2893,12 @@ static int linear_split_pack_impl(const float* W, const float* mask, const float
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;
     unsigned* slot = (unsigned*)(ktab + 2 * nt);
-    hipError_t me = hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), s);
-    if (me != hipSuccess) return (int)me;
+    // the scale pair behind the table: rewritten per pack by the f16x2 flavour only (atomic max into zeros); the other
+    // flavours never touch it again after the first pack - no 8-byte memset launch per layer and optimizer step
+    if (dtype == NF_DTYPE_F16X2 || table) {
+        hipError_t me = hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), s);
+        if (me != hipSuccess) return (int)me;
+    }
     if (dtype == NF_DTYPE_F16X2) {
         const int64_t nw = (int64_t)out * in;
         const int mgrid = out < 1024 ? out : 1024;

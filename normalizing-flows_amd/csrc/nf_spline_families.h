@@ -791,7 +791,7 @@ __device__ __forceinline__ float cubic_bwd_eval_t(float* p, float x, float gy, f
     const bool first = b == 0, last = b == K - 1;
     // one sigmoid serves whichever end bin the element sits in (K >= 2: never both)
     const float ue = first ? ul : ur;
-    const float sig = nf_div_ieee(1.0f, nf_divisor(1.0f + nf_exp(-ue)));
+    const float sig = 1.0f / (1.0f + nf_exp(-ue));          // (`/`: the denominator may be +inf)
     const NfDivisor dl01 = nf_divisor(w0 + wb), dr01 = nf_divisor(wb + w1);
     const float m2l = nf_div_ieee(0.5f * (wb * s0 + w0 * sb), dl01);
     const float m2r = nf_div_ieee(0.5f * (w1 * sb + wb * s1), dr01);

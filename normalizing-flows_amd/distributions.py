@@ -106,19 +106,23 @@ class StandardNormal(Distribution):
         return self.log_prob_plus(inputs, None, 1.0)
 
     def log_prob_plus(self, inputs, logabsdet, sign=1.0):
-        """log N(inputs; 0, I) + sign * logabsdet.  On the GPU, outside autograd, one launch (nf_std_normal_log_prob)
-        instead of the pow / mul / add / sum / add chain; under autograd the reference's ops (differentiable)."""
+        """log N(inputs; 0, I) + sign * logabsdet.  On the GPU one launch (nf_std_normal_log_prob) instead of the
+        pow / mul / add / sum / add chain, under autograd through autograd.StdNormalLogProbFn; elsewhere the reference's
+        ops."""
         if inputs.shape[1:] != self._shape:
             raise ValueError('Expected input of shape {}, got {}'.format(self._shape, inputs.shape[1:]))
         n = inputs.shape[0]
         recording = torch.is_grad_enabled() and (inputs.requires_grad or
                                                  (logabsdet is not None and logabsdet.requires_grad))
-        if inputs.is_cuda and inputs.dtype == torch.float32 and not recording and n > 0 and \
+        if inputs.is_cuda and inputs.dtype == torch.float32 and n > 0 and \
                 (logabsdet is None or logabsdet.dtype == torch.float32):
-            from . import _lib
             z = inputs.reshape(n, -1)
             if z.stride(1) != 1:
                 z = z.contiguous()
+            if recording:
+                from .autograd import StdNormalLogProbFn
+                return StdNormalLogProbFn.apply(z, logabsdet, sign)
+            from . import _lib
             return _lib.std_normal_log_prob(z, logabsdet, sign)
         lp = (-0.5 * inputs.pow(2) - 0.5 * math.log(2 * math.pi)).reshape(n, -1).sum(dim=1)
         return lp if logabsdet is None else lp + sign * logabsdet

@@ -200,6 +200,12 @@ class GradientSynchronizer:
             self._make_bucket(cur)
         self._defer = False
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        # the package's own autograd nodes accumulate weight gradients straight into these views (autograd._grad_sink)
+        # and call the hooks themselves: use loss.backward(), not torch.autograd.grad, on these parameters meanwhile
+        from . import autograd as _ag
+        _ag._engine_fires_post_accumulate_hooks_without_a_gradient()      # (probed here, outside any backward pass)
+        for p in self.params:
+            p._nf_grad_sink = True
 
     def no_sync(self):
         """Context manager for gradient accumulation: backward passes inside it only add into the flat buffers; the
@@ -277,6 +283,8 @@ class GradientSynchronizer:
     def remove(self):
         for h in self._handles:
             h.remove()
+        for p in self.params:
+            p._nf_grad_sink = False
 
 
 class _SyncBatchNormFn(torch.autograd.Function):

@@ -2591,10 +2591,18 @@ def test_half_precision_weight_gradient_transposed_read_kernel(nf, shape):
 @pytest.mark.parametrize('mode', ['f32', 'bf16', 'f16x2'])
 def test_gradient_synchronizer_through_the_hip_autograd_functions(nf, mode):
     """parallel.GradientSynchronizer at world size 1 around a training step of a small RQ-spline MAF whose backward
-    runs through MaskedLinearFn / FinalRqsFn / RqsFn (fresh gradient tensors accumulated into the flat bucket views):
-    zero_grad -> backward -> finish gives the gradients of the plain step, `.grad` is still the flat view afterwards,
-    a second step re-uses the views, and Adam steps on them move the weights like the plain optimizer's."""
+    runs through MaskedLinearFn / FinalRqsFn / RqsFn.  The weight-gradient kernels of a synchronised model accumulate
+    straight into the flat bucket views (autograd._grad_sink: no zero-filled temporaries, no AccumulateGrad adds) and
+    the nodes fire the parameters' post-accumulate hooks themselves - every bucket must have counted down to zero when
+    backward returns: zero_grad -> backward -> finish gives the gradients of the plain step (fresh tensors through
+    AccumulateGrad), `.grad` is still the flat view afterwards, a second step re-uses the views, Adam steps on them
+    move the weights like the plain optimizer's, and two backward passes under no_sync() leave twice the gradient."""
+    from importlib import import_module
     from normalizing_flows_amd import parallel
+    ag = import_module(nf.__name__ + '.autograd')
+    sunk = []
+    orig_done = ag._sink_done
+    ag._sink_done = lambda *ps: (sunk.append(len(ps)), orig_done(*ps))[1]
     D, H, K, B, Tb = 24, 64, 8, 256, 3.0
     sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=90 + j, scale=0.1) for j in range(2)]
     x = (torch.randn(B, D, generator=torch.Generator().manual_seed(8)) * 1.2).cuda()
@@ -2612,7 +2620,11 @@ def test_gradient_synchronizer_through_the_hip_autograd_functions(nf, mode):
             opt_p.zero_grad(set_to_none=True)
             (-plain.log_prob(x).mean()).backward()
             sync.zero_grad()
+            del sunk[:]
             (-synced.log_prob(x).mean()).backward()
+            # every MaskedLinear of both layers (initial + 2 x 2 block linears + final = 6 each) took the direct path
+            assert len(sunk) == 12, sunk
+            assert all(b['pending'] == 0 for b in sync.buckets)
             assert sync.finish() == 0                       # (no collective at world size 1)
             for (k, p), q in zip(plain.named_parameters(), synced.parameters()):
                 b, v = sync._bucket_of[q]
@@ -2631,12 +2643,62 @@ def test_gradient_synchronizer_through_the_hip_autograd_functions(nf, mode):
             assert torch.allclose(p[big], q[big], rtol=0, atol=1e-4), k
             moved += int(big.sum())
         assert moved > 1000
+        # gradient accumulation: two passes under no_sync() add up in the views
+        sync.zero_grad()
+        (-synced.log_prob(x).mean()).backward()
+        sync.finish()
+        once = [q.grad.clone() for q in synced.parameters()]
+        sync.zero_grad()
+        with sync.no_sync():
+            (-synced.log_prob(x).mean()).backward()
+            (-synced.log_prob(x).mean()).backward()
+        sync.finish()
+        for q, g1 in zip(synced.parameters(), once):
+            assert (q.grad - 2 * g1).abs().max().item() <= 4e-5 * (g1.abs().max().item() + 1e-20)
         # a second backward with no finish() / zero_grad() between is refused instead of silently racing a collective
+        sync.zero_grad()
         with pytest.raises(RuntimeError):
             (-synced.log_prob(x).mean()).backward()
             (-synced.log_prob(x).mean()).backward()
+        # detached from the synchronizer the parameters go through AccumulateGrad again
+        sync.finish()
+        sync.remove()
+        del sunk[:]
+        for q in synced.parameters():
+            q.grad = None
+        (-synced.log_prob(x).mean()).backward()
+        assert not sunk
+        for q, g1 in zip(synced.parameters(), once):
+            assert (q.grad - g1).abs().max().item() <= 2e-5 * (g1.abs().max().item() + 1e-20)
     finally:
+        ag._sink_done = orig_done
         nf.set_matmul_dtype('f32')
+
+
+def test_std_normal_log_prob_under_autograd(nf):
+    """StandardNormal.log_prob_plus records ONE node (autograd.StdNormalLogProbFn on nf_std_normal_log_prob): values and
+    both gradients against the reference's op chain (distributions.py there: -z^2 / 2 - log(2 pi) / 2 summed, plus the
+    log-determinant) in float64, for both signs of the log-determinant term and without one."""
+    g = torch.Generator().manual_seed(4)
+    B, D = 300, 37
+    z = torch.randn(B, D, generator=g)
+    lad = torch.randn(B, generator=g)
+    w = torch.randn(B, generator=g)
+    base = nf.StandardNormal([D]).cuda()
+    for sign, with_lad in ((1.0, True), (-1.0, True), (1.0, False)):
+        zc, lc = z.cuda().requires_grad_(True), lad.cuda().requires_grad_(True)
+        out = base.log_prob_plus(zc, lc if with_lad else None, sign)
+        assert out.grad_fn is not None and 'StdNormalLogProbFn' in type(out.grad_fn).__name__
+        (out * w.cuda()).sum().backward()
+        z64, l64 = z.double().requires_grad_(True), lad.double().requires_grad_(True)
+        ref = (-0.5 * z64.pow(2) - 0.5 * np.log(2 * np.pi)).sum(1) + (sign * l64 if with_lad else 0.0)
+        (ref * w.double()).sum().backward()
+        assert_close(out.detach(), ref.detach())
+        assert_close(zc.grad, z64.grad)
+        if with_lad:
+            assert_close(lc.grad, l64.grad)
+        else:
+            assert lc.grad is None
 
 
 @pytest.mark.parametrize('B', [513, 600, 1000, 1300])
