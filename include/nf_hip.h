@@ -350,6 +350,15 @@ int nf_masked_linear_split_bwd_input(const float* grad_y, int64_t grad_y_row_str
                                      const float* gate, int64_t gate_row_stride, float* grad_x,
                                      int64_t grad_x_row_stride, uint32_t* grad_x_max, int64_t B, int out, int in, int dtype,
                                      void* stream);
+/* The same with a second gradient joining behind the gate: grad_x = gate(grad_y @ (W * mask)) + add[B, in] - the
+ * gradient that reaches a residual block's input along its skip connection (made.py:284 `inputs + temps`; autograd
+ * sums the two there with an add pass, and the next split-operand launch needs a max pass over the sum).  gate and add
+ * are required; grad_x_max is max |grad_x| of the sum. */
+int nf_masked_linear_split_bwd_input_add(const float* grad_y, int64_t grad_y_row_stride, const uint32_t* grad_y_max,
+                                         const void* packed_wt, const int32_t* ktab_t, const float* bias_zero,
+                                         const float* gate, int64_t gate_row_stride, const float* add,
+                                         int64_t add_row_stride, float* grad_x, int64_t grad_x_row_stride,
+                                         uint32_t* grad_x_max, int64_t B, int out, int in, int dtype, void* stream);
 
 /* ---- coupling conditioner: the ResidualNet's hidden stack in one launch ------------------------------
  *      (replaces resnet.py:96-98 `initial_layer` + `blocks` and the `inputs[:, identity_features]` gather of

@@ -154,6 +154,10 @@ _SIGNATURES = {
     'nf_masked_linear_split_bwd_input': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                     _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
                                                     _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    'nf_masked_linear_split_bwd_input_add': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                                        _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                                                        _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int,
+                                                        _c.c_int, _c.c_int, _c.c_void_p]),
     'nf_masked_linear_split_fwd': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                               _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
                                               _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -400,10 +404,11 @@ def maxabs(x):
 
 
 def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, out=None, x_max=None, gate=None,
-                        reverse_k=False):
+                        reverse_k=False, add=None):
     """Split-operand hidden-layer GEMM.  The result is tagged (tag_max) with the slot holding max |out| so that a
     following split-operand launch needs no pass over it; x's own slot (`x_max`, else its valid tag) is used when
-    present, else computed here."""
+    present, else computed here.  add (with reverse_k and a gate): a second gradient joining behind the gate
+    (nf_masked_linear_split_bwd_input_add)."""
     lib = load()
     _dev(x, 'x')
     xp, xs = _rows(x, 'x')
@@ -427,8 +432,19 @@ def masked_linear_split(x, pls, residual=None, relu_in=False, relu_out=False, ou
 
     if reverse_k and (relu_in or (residual is not None and gate is None) or relu_out == 1):
         raise ValueError('reverse_k is the input-gradient launch: x = grad_y, pls = the transposed pack, optional gate')
+    if add is not None:
+        if not reverse_k or gate is None:
+            raise ValueError('add joins an input-gradient launch behind its gate (reverse_k, gate)')
+        if add.shape != out.shape:
+            raise ValueError('add: expected shape %s, got %s' % (tuple(out.shape), tuple(add.shape)))
+        ap, as_ = _rows(_dev(add, 'add'), 'add')
 
     def launch():
+        if add is not None:
+            return lib.nf_masked_linear_split_bwd_input_add(xp, xs, _ptr(x_max), pls.packed.data_ptr(),
+                                                            pls.ktab.data_ptr(), pls.bias.data_ptr(), rp, rs, ap, as_, yp,
+                                                            ys, y_max.data_ptr(), B, pls.inp, pls.out, pls.dtype,
+                                                            _stream())
         if reverse_k:       # nf_masked_linear_split_bwd_input: the live K ranges walked from their (common) end down
             return lib.nf_masked_linear_split_bwd_input(xp, xs, _ptr(x_max), pls.packed.data_ptr(), pls.ktab.data_ptr(),
                                                         pls.bias.data_ptr(), rp, rs, yp, ys, y_max.data_ptr(), B,

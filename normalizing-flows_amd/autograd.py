@@ -11,6 +11,8 @@ model.py:233-244).  Here every forward kernel has a hand-written backward kernel
                    implicitly at its output (nf_rqs_inverse_bwd)
   AffineFn       : (y, logabsdet) = sigmoid-scale affine(x; params), either direction, AR or coupling layout
                    backward: recompute-from-inputs kernel nf_rqs_bwd -> grad_x, grad_params
+  ResidualBlockFn : a plain MADE residual block as one node: the skip connection's gradient joins the first layer's
+                   input-gradient GEMM in its epilogue (nf_masked_linear_split_bwd_input_add)
   StdNormalLogProbFn : log N(z; 0, I) + sign * logabsdet, one launch (nf_std_normal_log_prob)
   FinalRqsFn     : final MADE layer + RQ spline of a whole autoregressive layer as ONE node (f32 / bf16 modes): forward
                    nf_made_rqs_fwd_params (the parameters kept, not re-read between GEMM and spline); backward
@@ -129,9 +131,10 @@ class MaskedLinearFn(torch.autograd.Function):
         return gx, gw, gb, gres, None, None
 
 
-def _linear_backward(layer, x, grad_y, relu_in, x_max, want_x, want_w, has_bias, into=None):
+def _linear_backward(layer, x, grad_y, relu_in, x_max, want_x, want_w, has_bias, into=None, add=None):
     """(grad_x, grad_W, grad_b) of y = act_in(x) @ (W*mask)^T + b from grad_y, in the current matrix mode (`into`: the
-    pair the weight gradient is accumulated into instead of fresh tensors, _grad_sink)."""
+    pair the weight gradient is accumulated into instead of fresh tensors, _grad_sink; `add`: a gradient that joins
+    grad_x, in the input-gradient GEMM's epilogue where that kernel takes it)."""
     gx = gw = gb = None
     split_y = _split_mode(grad_y, layer.out_features)
     gy_max = _lib.tagged_max(grad_y)                   # left by the kernel that produced it (nf_rqs_bwd_max)
@@ -140,10 +143,17 @@ def _linear_backward(layer, x, grad_y, relu_in, x_max, want_x, want_w, has_bias,
     if want_x:
         if split_y:
             # dX = dY @ (W * mask): the same split-operand kernel on the transposed layer, ReLU gate in its epilogue
+            fuse = add is not None and relu_in
             gx = _lib.masked_linear_split(grad_y, layer._packed_linear_split_t(), x_max=gy_max,
-                                          gate=x if relu_in else None, reverse_k=True)
+                                          gate=x if relu_in else None, reverse_k=True, add=add if fuse else None)
+            if add is not None and not fuse:
+                gx = gx + add
         else:
             gx = _lib.masked_linear_bwd_input(grad_y, layer._packed_linear_t(), gate=x if relu_in else None)
+            if add is not None:
+                gx = gx + add
+    elif add is not None:
+        gx = add
     if want_w:
         if _bf16_mode() and _lib.split_gemm_supported(grad_y, layer.out_features):
             # bf16 mode: one scaled fp16 term per operand (11 bits against bf16's 8, same MFMA rate)
@@ -158,6 +168,58 @@ def _linear_backward(layer, x, grad_y, relu_in, x_max, want_x, want_w, has_bias,
             gw, gb = _lib.masked_linear_bwd_weight(x, grad_y, getattr(layer, 'mask', None),
                                                    layer._wgrad_ktab(), relu_in, want_bias=has_bias, into=into)
     return gx, gw, gb
+
+
+# One autograd node per plain residual block (False: two MaskedLinearFn nodes and autograd's own sum, A/B and tests)
+FUSED_RESIDUAL_BLOCK = True
+
+
+class ResidualBlockFn(torch.autograd.Function):
+    """y = x + ML1(relu(ML0(relu(x)))) - a MADE residual block without BatchNorm, dropout or context (made.py:268-284) -
+    as ONE node.  Forward: the two launches MaskedLinearFn makes.  Backward: the same four GEMMs, but the gradient that
+    reaches x along the skip connection joins the first layer's input-gradient GEMM in its epilogue
+    (nf_masked_linear_split_bwd_input_add) instead of in an add node of autograd's - which also left the sum without a
+    max tag, i.e. cost the next split-operand launch a pass over it: two [B, hidden] passes less per block and step."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, lin0, lin1):
+        split = _split_mode(x, lin0.in_features)
+        ctx.x_max = ctx.t_max = None
+        if split:
+            ctx.x_max = _lib.tagged_max(x)
+            if ctx.x_max is None:
+                ctx.x_max = _lib.maxabs(x)
+            t = _lib.masked_linear_split(x, lin0._packed_linear_split(), relu_in=True, x_max=ctx.x_max)
+            ctx.t_max = _lib.tagged_max(t)
+            y = _lib.masked_linear_split(t, lin1._packed_linear_split(), residual=x, relu_in=True, x_max=ctx.t_max)
+        else:
+            t = _lib.masked_linear(x, lin0._packed_linear(), relu_in=True)
+            y = _lib.masked_linear(t, lin1._packed_linear(), residual=x, relu_in=True)
+        ctx.save_for_backward(x, t)
+        ctx.layers = (lin0, lin1)
+        ctx.params = ((w0, b0), (w1, b1))
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, t = ctx.saved_tensors
+        lin0, lin1 = ctx.layers
+        (w0, b0), (w1, b1) = ctx.params
+        grad_y = grad_y.contiguous()
+        need = ctx.needs_input_grad
+        want0, want1 = need[1] or (b0 is not None and need[2]), need[3] or (b1 is not None and need[4])
+        sink1 = _grad_sink(w1, b1, b1 is not None) if want1 else None
+        gt, gw1, gb1 = _linear_backward(lin1, t, grad_y, True, ctx.t_max, True, want1, b1 is not None, into=sink1)
+        sink0 = _grad_sink(w0, b0, b0 is not None) if want0 else None
+        gx, gw0, gb0 = _linear_backward(lin0, x, gt, True, ctx.x_max, need[0], want0, b0 is not None, into=sink0,
+                                        add=grad_y)
+        if sink1 is not None:
+            _sink_done(w1, b1)
+            gw1 = gb1 = None
+        if sink0 is not None:
+            _sink_done(w0, b0)
+            gw0 = gb0 = None
+        return gx, gw0, gb0, gw1, gb1, None, None
 
 
 # bf16 training mode: keep the conditioner output of the fused training forward as bf16 (False: fp32, A/B and tests)

@@ -64,6 +64,8 @@ struct FusedArgs {
     int hmax_rows;           // t kernels: hmax is an array, one entry per group of 64 rows (planes from nf_made_hidden_planes_fwd)
     const float* residual;   // split hidden-layer GEMM: nullable [M, N] added to the output
     int64_t ldr;
+    const float* add2;       // split hidden-layer GEMM, relu_out == 2 only: nullable [M, N] added AFTER the gate (the skip
+    int64_t ldadd2;          // connection's gradient joining an input-gradient GEMM: no add pass, no max pass over the sum)
     int N, relu_out;         // split hidden-layer GEMM: output columns, ReLU on the output
     unsigned* out_max;       // split hidden-layer GEMM: nullable slot that receives max |output| (next layer's hmax)
     const void* hp;          // split-operand full launches: h pre-split into three bf16 term planes [3][M][hp_ld]
@@ -1019,13 +1021,15 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
                     ot[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * XOT + j * 32 + (lane & 31)] = acc[i][j][r];
 #pragma unroll
             for (int qh = 0; qh < 8; qh += 4) {
-                float4 rv[4];
+                float4 rv[4], av[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int64_t row = m0 + i * 32 + (qh + q) * 4 + (lane >> 4);
-                    rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    rv[q] = av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (g.residual && row < g.M && c0 < g.N)
                         rv[q] = *reinterpret_cast<const float4*>(g.residual + row * g.ldr + c0);
+                    if (g.add2 && row < g.M && c0 < g.N)
+                        av[q] = *reinterpret_cast<const float4*>(g.add2 + row * g.ldadd2 + c0);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1035,6 +1039,7 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
                     if (g.relu_out == 2) {          // `residual` is a gate: the ReLU derivative of an input-gradient GEMM
                         v.x = rv[q].x > 0.f ? v.x : 0.f; v.y = rv[q].y > 0.f ? v.y : 0.f;
                         v.z = rv[q].z > 0.f ? v.z : 0.f; v.w = rv[q].w > 0.f ? v.w : 0.f;
+                        v.x += av[q].x; v.y += av[q].y; v.z += av[q].z; v.w += av[q].w;
                     } else {
                         v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w;
                         if (g.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -1060,8 +1065,10 @@ __global__ __launch_bounds__(XT, 2) void masked_linear_split_kernel(const FusedA
                     const int64_t row = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < g.M) {
                         float v = SP::SCALED ? acc[i][j][r] * oscale : acc[i][j][r];
-                        if (g.relu_out == 2) v = g.residual[row * g.ldr + col] > 0.f ? v : 0.f;
-                        else {
+                        if (g.relu_out == 2) {
+                            v = g.residual[row * g.ldr + col] > 0.f ? v : 0.f;
+                            if (g.add2) v += g.add2[row * g.ldadd2 + col];
+                        } else {
                             if (g.residual) v += g.residual[row * g.ldr + col];
                             if (g.relu_out) v = fmaxf(v, 0.f);
                         }
@@ -2702,7 +2709,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
     FusedArgs g;
     g.c = nf_make_rqs_const(K, tails, tail_bound, min_bin_width, min_bin_height, min_derivative, 1.0);
     g.h = h; g.ldh = h_row_stride; g.w = packed_w; g.kpad = kpad_of(in); g.ktab = ktab; g.bias = bias_packed;
-    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.hmax_rows = 0; g.residual = nullptr; g.ldr = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max; g.vec_out = 0; g.k_reverse = 0;
+    g.x = x; g.ldx = x_row_stride; g.y = y; g.ldy = y_row_stride; g.partial = workspace; g.bins = bin_idx; g.feat_index = feat_index; g.hp = nullptr; g.hp_ld = 0; g.hmax = nullptr; g.hmax_rows = 0; g.residual = nullptr; g.ldr = 0; g.add2 = nullptr; g.ldadd2 = 0; g.N = 0; g.relu_out = 0; g.out_max = y_max; g.vec_out = 0; g.k_reverse = 0;
     g.M = B; g.K = in; g.D = features; g.fpt = fpt_of(g.c.P);
     g.fpt_magic = ((1u << 20) + g.fpt - 1) / g.fpt;
     g.params_out = params_out; g.ldp = params_row_stride; g.unfold = (float)(logit_div * 0.6931471805599453);
@@ -2963,9 +2970,10 @@ static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_
                              const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride,
                              uint32_t* y_max, int64_t B, int in, int out, int relu_in, int relu_out,
                              int dtype, int k_reverse, void* stream, const void* x_plane = nullptr,
-                             int64_t x_plane_stride = 0) {
+                             int64_t x_plane_stride = 0, const float* add2 = nullptr, int64_t add2_row_stride = 0) {
     if (B < 0 || in <= 0 || out <= 0) return NF_ERR_SHAPE;
     if (!linear_terms(dtype)) return NF_ERR_DTYPE;
+    if (add2 && (relu_out != 2 || add2_row_stride < out)) return NF_ERR_LAYOUT;     // (joins behind a gate only)
     // (a bf16 plane of the A operand: whole 16-wide K steps, 16-byte rows, no ReLU - NF_DTYPE_BF16 only)
     if (x_plane && (dtype != NF_DTYPE_BF16 || relu_in || in % XS != 0 || x_plane_stride < in || x_plane_stride % 8 != 0 ||
                     ((uintptr_t)x_plane & 15) != 0))
@@ -2987,10 +2995,12 @@ static int linear_split_impl(const float* x, int64_t x_row_stride, const uint32_
     g.m_tiles = (B + XM - 1) / XM; g.group_m = 8; g.k_reverse = k_reverse;
     g.wmax = (const unsigned*)(ktab + 2 * nt); g.hmax = (const unsigned*)x_max;
     g.residual = residual; g.ldr = res_row_stride; g.relu_out = relu_out; g.out_max = (unsigned*)y_max;
+    g.add2 = add2; g.ldadd2 = add2_row_stride;
     const int64_t grid = g.m_tiles * nt;
     if (grid > 0x7fffffff) return NF_ERR_SHAPE;
     g.vec_out = out % 4 == 0 && y_row_stride % 4 == 0 && ((uintptr_t)y & 15) == 0 &&
-                (!residual || (res_row_stride % 4 == 0 && ((uintptr_t)residual & 15) == 0));
+                (!residual || (res_row_stride % 4 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+                (!add2 || (add2_row_stride % 4 == 0 && ((uintptr_t)add2 & 15) == 0));
     const size_t stages = (size_t)2 * 2 * linear_terms(dtype) * XA, otile = sizeof(float) * (XT / 64) * 32 * XOT;
     const size_t lds = g.vec_out && otile > stages ? otile : stages;
     if (x_plane) {
@@ -3128,6 +3138,21 @@ extern "C" int nf_masked_linear_split_bwd_input(const float* grad_y, int64_t gra
                                                 int dtype, void* stream) {
     return linear_split_impl(grad_y, grad_y_row_stride, grad_y_max, packed_wt, ktab_t, bias_zero, gate, gate_row_stride,
                              grad_x, grad_x_row_stride, grad_x_max, B, out, in, 0, gate ? 2 : 0, dtype, 1, stream);
+}
+
+// nf_masked_linear_split_bwd_input whose result joins a second gradient: grad_x = gate(grad_y @ (W * mask)) + add
+// (`add` [B, in]: the gradient that reaches the same tensor along a skip connection - a residual block's input).  One
+// launch instead of the GEMM, an add pass and a max pass over the sum (grad_x_max is that of the sum).
+extern "C" int nf_masked_linear_split_bwd_input_add(const float* grad_y, int64_t grad_y_row_stride,
+                                                    const uint32_t* grad_y_max, const void* packed_wt,
+                                                    const int32_t* ktab_t, const float* bias_zero, const float* gate,
+                                                    int64_t gate_row_stride, const float* add, int64_t add_row_stride,
+                                                    float* grad_x, int64_t grad_x_row_stride, uint32_t* grad_x_max,
+                                                    int64_t B, int out, int in, int dtype, void* stream) {
+    if (!gate || !add) return NF_ERR_NULL;
+    return linear_split_impl(grad_y, grad_y_row_stride, grad_y_max, packed_wt, ktab_t, bias_zero, gate, gate_row_stride,
+                             grad_x, grad_x_row_stride, grad_x_max, B, out, in, 0, 2, dtype, 1, stream, nullptr, 0, add,
+                             add_row_stride);
 }
 
 extern "C" int nf_masked_linear_split_bwd_weight(const float* x, int64_t x_row_stride, const uint32_t* x_max,

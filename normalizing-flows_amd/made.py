@@ -348,6 +348,12 @@ class MaskedResidualBlock(nn.Module):
             if self.use_batch_norm:
                 s0, h0 = _bn_scale_shift(self.batch_norm_layers[0])
                 s1, h1 = _bn_scale_shift(self.batch_norm_layers[1])
+            elif context is None and (_training(self.linear_layers[0]) or _training(self.linear_layers[1]) or
+                                      (torch.is_grad_enabled() and inputs.requires_grad)):
+                from . import autograd as _ag
+                if _ag.FUSED_RESIDUAL_BLOCK:            # the whole block as one autograd node
+                    l0, l1 = self.linear_layers
+                    return _ag.ResidualBlockFn.apply(inputs, l0.weight, l0.bias, l1.weight, l1.bias, l0, l1)
             temps = self.linear_layers[0].fused(inputs, in_scale=s0, in_shift=h0, relu_in=True)
         if context is None:
             return self.linear_layers[1].fused(temps, in_scale=s1, in_shift=h1, relu_in=True, residual=inputs)

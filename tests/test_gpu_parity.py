@@ -2675,6 +2675,76 @@ def test_gradient_synchronizer_through_the_hip_autograd_functions(nf, mode):
         nf.set_matmul_dtype('f32')
 
 
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16'])
+@pytest.mark.parametrize('n_in', [64, 30])
+def test_input_gradient_gemm_with_a_joining_gradient(nf, mode, n_in):
+    """nf_masked_linear_split_bwd_input_add = nf_masked_linear_split_bwd_input followed by `+ add`, bit for bit (the sum
+    is taken on the same two fp32 values), with the max slot of the SUM; 16-byte rows (n_in = 64) and the scalar
+    epilogue (n_in = 30)."""
+    from normalizing_flows_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    B, n_out = 333, 72
+    w = (torch.randn(n_out, n_in, generator=g) * 0.2).cuda()
+    m = (torch.rand(n_out, n_in, generator=g) < 0.6).float().cuda()
+    gy = torch.randn(B, n_out, generator=g).cuda()
+    gate = torch.randn(B, n_in, generator=g).cuda()
+    add = torch.randn(B, n_in, generator=g).cuda()
+    pls = _lib.PackedLinearSplit(w, m, None, _lib.NF_DTYPE_F16X2 if mode == 'f16x2' else _lib.NF_DTYPE_BF16,
+                                 transposed=True)
+    plain = _lib.masked_linear_split(gy, pls, gate=gate, reverse_k=True)
+    fused = _lib.masked_linear_split(gy, pls, gate=gate, reverse_k=True, add=add)
+    assert torch.equal(fused, plain + add)
+    slot = _lib.tagged_max(fused)
+    assert slot is not None and slot.view(torch.float32).item() == fused.abs().max().item()
+    ref = (gy.double() @ (w * m).double()) * (gate > 0) + add.double()
+    tol = 2e-2 if mode == 'bf16' else 1e-5
+    assert (fused.double() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    with pytest.raises(ValueError):
+        _lib.masked_linear_split(gy, pls, reverse_k=True, add=add)            # joins behind a gate only
+
+
+@pytest.mark.parametrize('mode', ['f32', 'f16x2', 'bf16'])
+def test_residual_block_as_one_autograd_node(nf, mode):
+    """autograd.ResidualBlockFn (one node per plain residual block; the skip gradient joins the first layer's
+    input-gradient GEMM in its epilogue) against the two-node graph it replaces: same forward bits, input gradient equal
+    bit for bit (same kernels, and the join adds the same two values), weight gradients to the order of their fp32
+    atomics.  BatchNorm / context / dropout blocks keep the two-node graph."""
+    from importlib import import_module
+    ag = import_module(nf.__name__ + '.autograd')
+    D, H, K, B, Tb = 24, 64, 8, 300, 3.0
+    sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=40 + j, scale=0.1) for j in range(2)]
+    x = (torch.randn(B, D, generator=torch.Generator().manual_seed(9)) * 1.2).cuda()
+    nf.set_matmul_dtype(mode)
+    res = {}
+    try:
+        for fused in (True, False):
+            ag.FUSED_RESIDUAL_BLOCK = fused
+            flow = nf.BaseNeuralSplineFlow(nf.CompositeTransform(_load_layers(nf, sds, D, H, K, Tb)),
+                                           nf.StandardNormal([D])).cuda().train()
+            xi = x.clone().requires_grad_(True)
+            lp = flow.log_prob(xi)
+            names = set()
+            fn, seen = [lp.grad_fn], set()
+            while fn:
+                f = fn.pop()
+                if f is None or f in seen:
+                    continue
+                seen.add(f)
+                names.add(type(f).__name__)
+                fn.extend(n for n, _ in f.next_functions)
+            assert any('ResidualBlockFn' in n for n in names) == fused
+            (-lp.mean()).backward()
+            res[fused] = (lp.detach(), xi.grad, {k: p.grad for k, p in flow.named_parameters()})
+    finally:
+        ag.FUSED_RESIDUAL_BLOCK = True
+        nf.set_matmul_dtype('f32')
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
+    for k, gfused in res[True][2].items():
+        gtwo = res[False][2][k]
+        assert (gfused - gtwo).abs().max().item() <= 2e-5 * (gtwo.abs().max().item() + 1e-20), k
+
+
 def test_std_normal_log_prob_under_autograd(nf):
     """StandardNormal.log_prob_plus records ONE node (autograd.StdNormalLogProbFn on nf_std_normal_log_prob): values and
     both gradients against the reference's op chain (distributions.py there: -z^2 / 2 - log(2 pi) / 2 summed, plus the
