@@ -215,11 +215,12 @@ int nf_made_rqs_fwd_hmax(const float* h, int64_t h_row_stride, const uint32_t* h
 /* nf_made_rqs_fwd_params with the conditioner output kept as bf16 [B, features * P] (16-byte aligned, row stride in
  * elements) and the spline backward that reads it (forward direction, no pre-divisor; gradients as bf16 like
  * nf_rqs_bwd_max_bf16; D * P % 8 == 0).  For the bf16 training mode: everything derived from the kept parameters is
- * rounded to bf16 by the backward GEMMs anyway; y / logabsdet of the forward come from the fp32 accumulators.  No
- * counterpart in the reference (autograd keeps fp32 throughout). */
+ * rounded to bf16 by the backward GEMMs anyway; y / logabsdet of the forward come from the fp32 accumulators.
+ * y_max (nullable): receives the bit pattern of max |y| - the operand scale the next layer's weight gradient wants of
+ * its input, so no nf_maxabs pass over y.  No counterpart in the reference (autograd keeps fp32 throughout). */
 int nf_made_rqs_fwd_params_bf16(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
                                 const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
-                                int64_t y_row_stride, float* logabsdet, int accumulate, float* workspace,
+                                int64_t y_row_stride, uint32_t* y_max, float* logabsdet, int accumulate, float* workspace,
                                 size_t workspace_bytes, int64_t B, int in, int features, int K, int tails,
                                 double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
                                 int dtype, double logit_div, void* params_out_bf16, int64_t params_row_stride,

@@ -191,7 +191,7 @@ _SIGNATURES = {
                                           _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_double, _c.c_void_p,
                                           _c.c_int64, _c.c_void_p]),
     'nf_made_rqs_fwd_params_bf16': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
-                                               _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                               _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                                _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                                _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_double,
                                                _c.c_void_p, _c.c_int64, _c.c_void_p]),
@@ -916,17 +916,25 @@ def made_rqs_params(h, pf, x, tail_bound, min_bin_width=1e-3, min_bin_height=1e-
     logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
     params = torch.empty((B, pf.features * P), dtype=torch.bfloat16 if keep_bf16 else torch.float32, device=x.device)
     ws = fused_workspace(pf, B, x.device, planes=False)
-    fwd = lib.nf_made_rqs_fwd_params_bf16 if keep_bf16 else lib.nf_made_rqs_fwd_params
+    y_max = torch.empty(1, dtype=torch.int32, device=x.device) if keep_bf16 else None
 
     def launch():
-        return fwd(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs,
-                   yp, ys, logabsdet.data_ptr(), 0, ws.data_ptr(), ws.numel() * 4, B, pf.inp,
-                   pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
-                   float(min_bin_height), float(min_derivative), pf.dtype, float(logit_div),
-                   params.data_ptr(), params.stride(0), _stream())
+        if keep_bf16:       # (also leaves max |y|: the next layer's weight gradient scales its fp16 operand by it)
+            return lib.nf_made_rqs_fwd_params_bf16(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(),
+                                                   xp, xs, yp, ys, y_max.data_ptr(), logabsdet.data_ptr(), 0,
+                                                   ws.data_ptr(), ws.numel() * 4, B, pf.inp, pf.features, pf.K, pf.tails,
+                                                   float(tail_bound), float(min_bin_width), float(min_bin_height),
+                                                   float(min_derivative), pf.dtype, float(logit_div), params.data_ptr(),
+                                                   params.stride(0), _stream())
+        return lib.nf_made_rqs_fwd_params(hp, hs, pf.packed.data_ptr(), pf.ktab.data_ptr(), pf.bias.data_ptr(), xp, xs,
+                                          yp, ys, logabsdet.data_ptr(), 0, ws.data_ptr(), ws.numel() * 4, B, pf.inp,
+                                          pf.features, pf.K, pf.tails, float(tail_bound), float(min_bin_width),
+                                          float(min_bin_height), float(min_derivative), pf.dtype, float(logit_div),
+                                          params.data_ptr(), params.stride(0), _stream())
     with torch.cuda.device(x.device):
         code = launch() if _timer is None else _timer.record(('made_rqs', pf.inp, pf.features * P, B), launch)
         _check(code, 'nf_made_rqs_fwd_params')
+    tag_max(out, y_max)
     return out, logabsdet, params
 
 

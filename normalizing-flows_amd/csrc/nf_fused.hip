@@ -430,9 +430,20 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
         if (m0 + tid < g.M) g.partial[(int64_t)tn * g.M + m0 + tid] = s;
     }
     STAMP(e3)
+    float ymax = 0.f;
     for (int i = tid; i < FM * fpt; i += FT) {
         const int r = i / fpt, f = i - r * fpt;
-        if (m0 + r < g.M && f < fv) g.y[(m0 + r) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = xs[i];
+        if (m0 + r < g.M && f < fv) {
+            const float v = xs[i];
+            g.y[(m0 + r) * g.ldy + (g.feat_index ? g.feat_index[f0 + f] : f0 + f)] = v;
+            const float a = fabsf(v);
+            ymax = fmaxf(ymax, a < INFINITY ? a : 0.f);
+        }
+    }
+    if (g.out_max) {                                 // max |y|: the operand scale of whoever reads y next (see below)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+        if (lane == 0 && __float_as_uint(ymax) > __builtin_nontemporal_load(g.out_max)) atomicMax(g.out_max, __float_as_uint(ymax));
     }
 #ifdef NF_STAMP
     STAMP(tE)
@@ -444,12 +455,23 @@ __global__ __launch_bounds__(FT, NF_FOCC) void made_rqs_kernel(const FusedArgs g
 #endif
 }
 
-__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ partial, int n_tiles, int64_t M,
-                                                     float* __restrict__ lad, int accumulate) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// One row per lane, 64 rows per workgroup (32768 rows: 512 workgroups, not 128); the per-tile partial sums are added in
+// tile order (deterministic), eight loads in flight at a time - as a plain loop every load waited for the add before it.
+constexpr int kRowsumThreads = 64;
+__global__ __launch_bounds__(kRowsumThreads) void rowsum_kernel(const float* __restrict__ partial, int n_tiles, int64_t M,
+                                                                float* __restrict__ lad, int accumulate) {
+    const int64_t r = (int64_t)blockIdx.x * kRowsumThreads + threadIdx.x;
     if (r >= M) return;
     float s = 0.f;
-    for (int t = 0; t < n_tiles; ++t) s += partial[(int64_t)t * M + r];    // fixed order: deterministic
+    int t = 0;
+    for (; t + 8 <= n_tiles; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = partial[(int64_t)(t + i) * M + r];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; t < n_tiles; ++t) s += partial[(int64_t)t * M + r];
     lad[r] = accumulate ? lad[r] + s : s;
 }
 
@@ -2747,7 +2769,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
                 const size_t lds8 = (size_t)w8_ring_bytes(g.c.P, 1) + w8_xs_bytes(g.fpt, 1);
                 rc = inverse ? launch_k_t<true, 1>(g, (int)grid, lds8, s) : launch_k_t<false, 1>(g, (int)grid, lds8, s);
                 if (rc != NF_OK || !reduce) return rc;
-                hipLaunchKernelGGL(rowsum_kernel, dim3(nf_ceil_div(B, 256)), dim3(256), 0, s, workspace, all_tiles, B,
+                hipLaunchKernelGGL(rowsum_kernel, dim3(nf_ceil_div(B, kRowsumThreads)), dim3(kRowsumThreads), 0, s, workspace, all_tiles, B,
                                    logabsdet, accumulate);
                 return nf_launch_status();
             }
@@ -2765,7 +2787,7 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
             rc = inverse ? launch_k<false, true>(g, (int)grid, lds, s) : launch_k<false, false>(g, (int)grid, lds, s);
     }
     if (rc != NF_OK || !reduce) return rc;
-    hipLaunchKernelGGL(rowsum_kernel, dim3(nf_ceil_div(B, 256)), dim3(256), 0, s, workspace, all_tiles, B, logabsdet,
+    hipLaunchKernelGGL(rowsum_kernel, dim3(nf_ceil_div(B, kRowsumThreads)), dim3(kRowsumThreads), 0, s, workspace, all_tiles, B, logabsdet,
                        accumulate);
     return nf_launch_status();
 }
@@ -2864,17 +2886,17 @@ extern "C" int nf_made_rqs_fwd_params(const float* h, int64_t h_row_stride, cons
 // accumulators as in nf_made_rqs_fwd_params.
 extern "C" int nf_made_rqs_fwd_params_bf16(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
                                            const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
-                                           int64_t y_row_stride, float* logabsdet, int accumulate, float* workspace,
-                                           size_t workspace_bytes, int64_t B, int in, int features, int K, int tails,
-                                           double tail_bound, double min_bin_width, double min_bin_height,
-                                           double min_derivative, int dtype, double logit_div, void* params_out_bf16,
-                                           int64_t params_row_stride, void* stream) {
+                                           int64_t y_row_stride, uint32_t* y_max, float* logabsdet, int accumulate,
+                                           float* workspace, size_t workspace_bytes, int64_t B, int in, int features,
+                                           int K, int tails, double tail_bound, double min_bin_width,
+                                           double min_bin_height, double min_derivative, int dtype, double logit_div,
+                                           void* params_out_bf16, int64_t params_row_stride, void* stream) {
     if (!params_out_bf16) return NF_ERR_NULL;
     if (((uintptr_t)params_out_bf16 & 15) != 0) return NF_ERR_LAYOUT;
     return fused_fwd_impl(h, h_row_stride, packed_w, ktab, bias_packed, x, x_row_stride, y, y_row_stride, nullptr,
                           features, logabsdet, accumulate, nullptr, workspace, workspace_bytes, B, in, features, K, tails,
                           tail_bound, min_bin_width, min_bin_height, min_derivative, 0, dtype, 0,
-                          nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, nullptr, stream,
+                          nf_made_rqs_tiles(features, K, tails), features, 1, nullptr, (unsigned*)y_max, stream,
                           (float*)params_out_bf16, params_row_stride, logit_div, nullptr, nullptr, 1);
 }
 

@@ -2703,6 +2703,25 @@ def test_input_gradient_gemm_with_a_joining_gradient(nf, mode, n_in):
         _lib.masked_linear_split(gy, pls, reverse_k=True, add=add)            # joins behind a gate only
 
 
+def test_fused_training_forward_leaves_the_largest_output(nf):
+    """nf_made_rqs_fwd_params_bf16's y_max slot = max |y| exactly (the next layer's weight gradient takes its fp16
+    operand scale from it instead of a pass over y), ragged batch, and y equals the fp32-kept launch bit for bit."""
+    from normalizing_flows_amd import _lib
+    D, H, K, B, Tb = 40, 64, 8, 777, 3.0
+    sd = O.seeded_made_state_dict(D, H, 3 * K - 1, seed=5, scale=0.3)
+    w, m, b = (sd['autoregressive_net.final_layer.' + k].cuda() for k in ('weight', 'mask', 'bias'))
+    pf = _lib.PackedFusedFinal(w, m, b, D, K, 'linear', _lib.NF_DTYPE_BF16)
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(B, H, generator=g).relu().cuda()
+    x = (torch.randn(B, D, generator=g) * 2.5).cuda()
+    y16, lad16, p16 = _lib.made_rqs_params(h, pf, x, Tb, keep_bf16=True)
+    y32, lad32, p32 = _lib.made_rqs_params(h, pf, x, Tb, keep_bf16=False)
+    assert p16.dtype == torch.bfloat16 and torch.equal(y16, y32) and torch.equal(lad16, lad32)
+    slot = _lib.tagged_max(y16)
+    assert slot is not None and slot.view(torch.float32).item() == y16.abs().max().item()
+    assert _lib.tagged_max(y32) is None
+
+
 @pytest.mark.parametrize('mode', ['f32', 'f16x2', 'bf16'])
 def test_residual_block_as_one_autograd_node(nf, mode):
     """autograd.ResidualBlockFn (one node per plain residual block; the skip gradient joins the first layer's
