@@ -45,7 +45,7 @@ PEAK_HBM_GBS = 8000.0
 # summaries are committed under profiles/; the JSON line names the file next to the number (`traffic_source`).
 # Keyed by (dtype, fused kernel?, rows per launch); other shapes report null.
 TRAFFIC_BYTES_PER_LAUNCH = {('f32', True, 131072): (5.72e9, 'profiles/r01_h_f32_fused64_pmc.txt'),
-                            ('f16x2', True, 131072): (5.85e9, 'profiles/r03_b_f16x2_pmc.txt')}
+                            ('f16x2', True, 131072): (5.85e9, 'profiles/r03_c_f16x2_pmc.txt')}
 DTYPE_LABEL = {'f32': 'f32', 'bf16': 'bf16-mfma/f32-accumulate',
                'bf16x3': 'f32 as 3 bf16 terms (6 bf16 MFMA per product, f32 accumulate)',
                'f16x2': 'f32 as 2 fp16 terms (3 fp16 MFMA per product, f32 accumulate)'}
