@@ -423,7 +423,9 @@ extern "C" int nf_coupling_rqs_layer_fwd(const float* x, int64_t x_row_stride, f
     g.logabsdet = logabsdet; g.accumulate = accumulate; g.bins = bin_idx; g.M = B;
     g.nct = coupling_nct(features, g.c.P);
     g.ko = 0;
+#ifdef NF_TIMING_KNOBS      // timing-only builds (benchmarks/build_fused_variant.sh): phases knocked out, results wrong
     if (const char* e = getenv("NF_COUPLING_KO")) g.ko = atoi(e);
+#endif
     g.fc = 32 * g.nct / g.c.P;
     const size_t lds = coupling_lds(row_width, n_in, features, g.kp, hidden, g.nct, num_blocks);
     if (lds > 160 * 1024) return NF_ERR_SHAPE;

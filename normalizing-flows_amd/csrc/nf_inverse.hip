@@ -197,7 +197,8 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
             typedef const __attribute__((address_space(3))) float* lds_ptr;
             if constexpr (KT > 0) {
                 // lanes 32..63 build the width knots of the sample of lane - 32 (see rqs_inverse_pair)
-                const float zin = __shfl(rs[7], arow);
+                const float zother = nf_xor32(rs[7]);
+                const float zin = lane < IR ? rs[7] : zother;          // z of sample (lane & 31)
                 rqs_inverse_pair<KT, PSTR, lds_ptr>((lds_ptr)(prm + arow), zin, g.c, lane >= IR, y, ld, bin);
             }
             if (lane < IR) {
@@ -375,8 +376,8 @@ __global__ __launch_bounds__(IT, 1) void made_rqs_inverse_kernel(const InvArgs g
             for (int s = 0; s < NSTEP; ++s)
                 acc[s] = __builtin_amdgcn_mfma_f32_32x32x1f32(wcur[s], b[s * IR], acc[s], 0, 0, 0);
         }
-        {
-            // (each weight register is reloaded for the next round right after its use)
+        if (wave * 64 + 63 > j + 1) {                   // (a wave whose units are all finished has no update next round:
+            // each weight register is reloaded for the next round right after its use      wave 0 from round 62 on)
             const int64_t wrow = (int64_t)(j < H ? j : H - 1) * HS + kcol;
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) wcur[s] = g.wt[s][wrow];

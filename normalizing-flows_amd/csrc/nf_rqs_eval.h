@@ -269,6 +269,15 @@ __device__ __forceinline__ void rqs_eval(PT p, float x, const RqsConst& a, float
 // stream; the partners search the bin, fetch the two width knots of that bin by lane exchange and finish.  Same
 // operations in the same order as rqs_eval<KT, true> (pre_div = 1): y, ld, bin are valid in the lanes with
 // widths == false.
+// Value of lane (l ^ 32): gfx950's v_permlane32_swap_b32 exchanges the two 32-lane halves of a register pair on the
+// vector ALU - an LDS-path permute (ds_bpermute_b32, what __shfl_xor compiles to) costs an LDS round trip, and
+// rqs_inverse_pair sits on the row-resident inverse's critical path with three of them.  Every lane must be active.
+__device__ __forceinline__ int nf_xor32(int v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // {v with its upper half <- lower half,
+    return (__lane_id() & 32) ? (int)r[0] : (int)r[1];                       //  v with its lower half <- upper half}
+}
+__device__ __forceinline__ float nf_xor32(float v) { return __int_as_float(nf_xor32(__float_as_int(v))); }
+
 template <int KT, int STRIDE, class PT>
 __device__ __forceinline__ void rqs_inverse_pair(PT p, float x, const RqsConst& a, bool widths, float& y, float& ld,
                                                  int& bin) {
@@ -311,14 +320,14 @@ __device__ __forceinline__ void rqs_inverse_pair(PT p, float x, const RqsConst& 
     for (int k = 1; k < K; ++k)
         if (x >= kn[k]) { b = k; y0 = kn[k]; y1 = kn[k + 1]; }
     // the width lanes pick the knots of their partner's bin and hand them over
-    const int bpartner = __shfl_xor(b, 32);          // (unconditional: a lane exchange inside a divergent branch reads inactive lanes)
+    const int bpartner = nf_xor32(b);                // (unconditional: a lane exchange inside a divergent branch reads inactive lanes)
     const int bsel = widths ? bpartner : b;
     float x0 = kn[0], x1 = kn[1];
 #pragma unroll
     for (int k = 1; k < K; ++k)
         if (bsel == k) { x0 = kn[k]; x1 = kn[k + 1]; }
-    x0 = __shfl_xor(x0, 32);
-    x1 = __shfl_xor(x1, 32);
+    x0 = nf_xor32(x0);
+    x1 = nf_xor32(x1);
 
     float u0, u1;
     if (a.tails) {
