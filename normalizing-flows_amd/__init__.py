@@ -1,6 +1,7 @@
 """MI355X-native flow-transform hot path (MADE conditioner -> affine / RQ-spline transform ->
 per-sample log|det J|) behind the reference's module API.  See DESIGN.md."""
 from . import _lib
+from ._lib import invalidate_weight_caches
 from .made import MADE, MaskedLinear, DenseLinear, MaskedResidualBlock, MaskedFeedforwardBlock, \
     set_matmul_dtype, get_matmul_dtype
 from .resnet import ResidualNet, ResidualBlock

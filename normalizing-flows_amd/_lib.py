@@ -370,6 +370,37 @@ class PackedLinearSplit:
                           self.ktab.data_ptr(), self.bias.data_ptr(), _stream()), 'nf_linear_split_pack')
 
 
+# ---- weight-cache generation ------------------------------------------------------------------------------------------
+# The packed copies of a layer's weights are cached on (tensor version, storage address, ...).  Not every writer bumps
+# the version counter: torch's fused optimizers (Adam(fused=True) ...) update the parameters with one kernel that leaves
+# `_version` alone - a cache keyed on versions only would keep serving the OLD weights after such a step, silently.  So
+# every cache key also carries this generation, which any optimizer step in the process advances (a global
+# post-step hook, registered on first import), and which callers that write parameters behind torch's back
+# (custom kernels, raw storage writes) advance themselves with invalidate_weight_caches().
+_WEIGHT_GENERATION = [0]
+
+
+def invalidate_weight_caches():
+    """Make every cached weight pack stale (they are rebuilt at their next use)."""
+    _WEIGHT_GENERATION[0] += 1
+
+
+def weight_version(t):
+    """Cache-key element for a parameter / buffer tensor: (version counter, weight-cache generation)."""
+    return (t._version, _WEIGHT_GENERATION[0])
+
+
+def _register_optimizer_hook():
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+    except ImportError:             # (then only version-bumping writers are seen; invalidate_weight_caches() remains)
+        return
+    register_optimizer_step_post_hook(lambda optimizer, args, kwargs: invalidate_weight_caches())
+
+
+_register_optimizer_hook()
+
+
 def split_gemm_supported(x, in_features):
     """Shapes the split-operand hidden-layer kernel takes: 16-byte rows, in_features a multiple of 8."""
     return (in_features % 8 == 0 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0

@@ -30,7 +30,7 @@ class SimpleMaskedLinear(nn.Linear):
         object.__setattr__(self, '_folded', None)
 
     def folded(self):
-        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        key = (_lib.weight_version(self.weight), self.weight.data_ptr(), self.weight.device)
         c = getattr(self, '_folded', None)
         if c is None or c[0] != key:
             mask = None if self.mask is None else torch.as_tensor(self.mask).to(self.weight.device)

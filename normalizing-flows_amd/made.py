@@ -81,7 +81,7 @@ class _PackedMixin:
     def _packed_linear(self):
         mask = getattr(self, 'mask', None)
         mkey = None if mask is None else (mask._version, mask.data_ptr())
-        key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
+        key = (_lib.weight_version(self.weight), self.weight.data_ptr(), None if self.bias is None else _lib.weight_version(self.bias),
                get_matmul_dtype(), self.weight.device, mkey)
         cached = getattr(self, '_pack_cache', None)
         if cached is None or cached[0] != key:
@@ -95,7 +95,7 @@ class _PackedMixin:
     def _packed_linear_split(self):
         """Term-plane pack for the split-operand hidden-layer kernel (nf_linear_split_pack), cached likewise."""
         mask = getattr(self, 'mask', None)
-        key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
+        key = (_lib.weight_version(self.weight), self.weight.data_ptr(), None if self.bias is None else _lib.weight_version(self.bias),
                get_matmul_dtype(), self.weight.device, None if mask is None else (mask._version, mask.data_ptr()))
         cached = getattr(self, '_split_cache', None)
         if cached is None or cached[0] != key:
@@ -109,7 +109,7 @@ class _PackedMixin:
     def _packed_linear_split_t(self):
         """Term-plane pack of the transposed layer (input-gradient GEMM in the split-operand modes), cached likewise."""
         mask = getattr(self, 'mask', None)
-        key = (self.weight._version, self.weight.data_ptr(), get_matmul_dtype(), self.weight.device,
+        key = (_lib.weight_version(self.weight), self.weight.data_ptr(), get_matmul_dtype(), self.weight.device,
                None if mask is None else (mask._version, mask.data_ptr()))
         cached = getattr(self, '_split_t_cache', None)
         if cached is None or cached[0] != key:
@@ -135,7 +135,7 @@ class _PackedMixin:
         """Final layer regrouped for the fused GEMM + spline kernel (nf_made_rqs_pack), cached likewise."""
         mask = getattr(self, 'mask', None)
         mkey = None if mask is None else (mask._version, mask.data_ptr())
-        key = (self.weight._version, self.weight.data_ptr(), None if self.bias is None else self.bias._version,
+        key = (_lib.weight_version(self.weight), self.weight.data_ptr(), None if self.bias is None else _lib.weight_version(self.bias),
                get_matmul_dtype(), self.weight.device, features, num_bins, tails, float(logit_div), mkey)
         cached = getattr(self, '_fused_cache', None)
         if cached is None or cached[0] != key:
@@ -152,7 +152,7 @@ class _PackedMixin:
         mask = getattr(self, 'mask', None)
         mkey = None if mask is None else (mask._version, mask.data_ptr())
         dtype = _GEMM_DTYPE[get_matmul_dtype()]         # bf16 mode: the input-gradient GEMM runs on bf16 MFMA too
-        key = (self.weight._version, self.weight.data_ptr(), self.weight.device, dtype, mkey)
+        key = (_lib.weight_version(self.weight), self.weight.data_ptr(), self.weight.device, dtype, mkey)
         cached = getattr(self, '_pack_t_cache', None)
         if cached is None or cached[0] != key:
             same_mask = cached is not None and cached[0][-1] == mkey
@@ -454,7 +454,7 @@ class MADE(nn.Module):
             return None
         steps, _ = self.hidden_program()
         layers = [st[0] for st in steps]
-        key = tuple((l.weight._version, l.weight.data_ptr(), None if l.bias is None else l.bias._version,
+        key = tuple((_lib.weight_version(l.weight), l.weight.data_ptr(), None if l.bias is None else _lib.weight_version(l.bias),
                      l.mask._version, l.mask.data_ptr()) for l in layers) + (self.initial_layer.weight.device,)
         cached = getattr(self, '_hidden_planes_cache', None)
         if cached is not None and cached[0] == key:
@@ -495,12 +495,12 @@ class MADE(nn.Module):
             return None
         steps, _ = self.hidden_program()
         layers = [st[0] for st in steps] + [self.final_layer]
-        key = (kind,) + tuple((l.weight._version, l.weight.data_ptr(), None if l.bias is None else l.bias._version,
+        key = (kind,) + tuple((_lib.weight_version(l.weight), l.weight.data_ptr(), None if l.bias is None else _lib.weight_version(l.bias),
                      l.mask._version) for l in layers) + (self.final_layer.weight.device, num_bins, tails)
         for st in steps:
             if st[6] is not None:
                 bn = st[6]
-                key += (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+                key += (_lib.weight_version(bn.weight), _lib.weight_version(bn.bias), bn.running_mean._version, bn.running_var._version,
                         bn.training)
         cached = getattr(self, '_inverse_rows_cache', None)
         if cached is not None and cached[0] == key:

@@ -90,7 +90,7 @@ class ResidualNet(nn.Module):
                     bn = blk.batch_norm_layers[j]
                     tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
                 tensors += [blk.linear_layers[j].weight, blk.linear_layers[j].bias]
-        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.initial_layer.weight.device,)
+        key = tuple((t.data_ptr(), _lib.weight_version(t)) for t in tensors) + (self.initial_layer.weight.device,)
         cached = getattr(self, '_blob_cache', None)
         if cached is None or cached[0] != key:
             with torch.no_grad():

@@ -660,7 +660,8 @@ class PiecewiseRationalQuadraticCouplingTransform(CouplingTransform):
     def _packed_coupling_final(self):
         """The conditioner's final Linear for the one-launch layer kernel (nf_coupling_final_pack), cached."""
         fl = self.transform_net.final_layer
-        key = (fl.weight._version, fl.weight.data_ptr(), None if fl.bias is None else fl.bias._version, fl.weight.device,
+        key = (_lib.weight_version(fl.weight), fl.weight.data_ptr(), None if fl.bias is None else _lib.weight_version(fl.bias),
+               fl.weight.device,
                self.num_bins, self.tails, float(self._pre_div()))
         cached = self.__dict__.get('_coupling_final_cache')
         if cached is None or cached[0] != key:

@@ -2764,6 +2764,47 @@ def test_residual_block_as_one_autograd_node(nf, mode):
         assert (gfused - gtwo).abs().max().item() <= 2e-5 * (gtwo.abs().max().item() + 1e-20), k
 
 
+@pytest.mark.parametrize('mode', ['f32', 'f16x2'])
+def test_weight_packs_follow_a_fused_optimizer_step(nf, mode):
+    """torch's fused optimizers write the parameters without touching their version counters; the packed copies of the
+    weights (cached per layer) must still be rebuilt - every optimizer step advances the cache generation
+    (_lib.weight_version).  After Adam(fused=True) steps the model must compute what a fresh model loaded with the
+    updated state_dict computes, in training and in inference (one-launch hidden stack / fused layer packs included)."""
+    D, H, K, B, Tb = 24, 64, 8, 200, 3.0
+    sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=60 + j, scale=0.1) for j in range(2)]
+    x = (torch.randn(B, D, generator=torch.Generator().manual_seed(2)) * 1.2).cuda()
+    nf.set_matmul_dtype(mode)
+    try:
+        def make():
+            return nf.BaseNeuralSplineFlow(nf.CompositeTransform(_load_layers(nf, sds, D, H, K, Tb)),
+                                           nf.StandardNormal([D])).cuda()
+        flow = make()
+        with torch.no_grad():
+            before = flow.eval().log_prob(x)                      # (packs of the inference paths now cached)
+        flow.train()
+        opt = torch.optim.Adam(flow.parameters(), lr=1e-2, fused=True)
+        versions = [p._version for p in flow.parameters()]
+        for _ in range(2):
+            opt.zero_grad()
+            (-flow.log_prob(x).mean()).backward()
+            opt.step()
+        if [p._version for p in flow.parameters()] != versions:
+            pytest.skip('this torch bumps version counters in its fused optimizer: nothing to guard against')
+        fresh = make()
+        fresh.load_state_dict(flow.state_dict())
+        with torch.no_grad():
+            after, want = flow.eval().log_prob(x), fresh.eval().log_prob(x)
+        assert torch.equal(after, want)
+        assert (after - before).abs().max().item() > 1e-2
+        lp_train, lp_fresh = flow.train().log_prob(x), fresh.train().log_prob(x)
+        assert torch.equal(lp_train.detach(), lp_fresh.detach())
+        gen = nf._lib._WEIGHT_GENERATION[0]
+        nf.invalidate_weight_caches()
+        assert nf._lib._WEIGHT_GENERATION[0] == gen + 1
+    finally:
+        nf.set_matmul_dtype('f32')
+
+
 def test_std_normal_log_prob_under_autograd(nf):
     """StandardNormal.log_prob_plus records ONE node (autograd.StdNormalLogProbFn on nf_std_normal_log_prob): values and
     both gradients against the reference's op chain (distributions.py there: -z^2 / 2 - log(2 pi) / 2 summed, plus the
