@@ -789,6 +789,8 @@ def made_rqs(h, pf, x, tail_bound, inverse=False, out=None, logabsdet=None, accu
                              % pf.features)
     if out is None:
         out = torch.empty_like(x)
+    else:
+        tag_max(out, None)              # (a max slot left by an earlier writer no longer describes this buffer)
     yp, ys = _rows(out, 'outputs')
     if logabsdet is None:
         logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
@@ -900,6 +902,8 @@ def made_rqs_planes(planes, row_scale, pf, x, tail_bound, inverse=False, out=Non
         raise ValueError('made_rqs_planes: f16x2 pack and inputs [B,%d]' % pf.features)
     if out is None:
         out = torch.empty_like(x)
+    else:
+        tag_max(out, None)              # (a max slot left by an earlier writer no longer describes this buffer)
     yp, ys = _rows(out, 'outputs')
     if logabsdet is None:
         logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
@@ -1305,6 +1309,8 @@ def rqs(x, params, num_bins, tails, tail_bound, inverse=False, pre_div=1.0, feat
     pp, ps = _rows(params, 'params')
     if out is None:
         out = torch.empty_like(x)
+    else:
+        tag_max(out, None)              # (a max slot left by an earlier writer no longer describes this buffer)
     yp, ys = _rows(out, 'outputs')
     if logabsdet is None:
         logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
@@ -1330,6 +1336,8 @@ def _family_call(x, params, out, logabsdet, accumulate, want_bins, num_features)
     pp, ps = _rows(params, 'params')
     if out is None:
         out = torch.empty_like(x)
+    else:
+        tag_max(out, None)              # (a max slot left by an earlier writer no longer describes this buffer)
     yp, ys = _rows(out, 'outputs')
     if logabsdet is None:
         logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
@@ -1441,6 +1449,8 @@ def affine(x, params, layout, inverse=False, feat_index=None, out=None, logabsde
     pp, ps = _rows(params, 'params')
     if out is None:
         out = torch.empty_like(x)
+    else:
+        tag_max(out, None)              # (a max slot left by an earlier writer no longer describes this buffer)
     yp, ys = _rows(out, 'outputs')
     if logabsdet is None:
         logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
