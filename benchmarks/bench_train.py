@@ -26,7 +26,16 @@ def main():
     ap.add_argument('--layers', type=int, default=5)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16x2', 'bf16x3', 'bf16'],
                     help='matrix mode of the forward and input-gradient GEMMs (weight gradients: fp32 MFMA)')
+    ap.add_argument('--two-launch-forward', action='store_true',
+                    help='final layer + spline of the training forward as two autograd nodes (A/B of the fused forward)')
+    ap.add_argument('--fused-forward-f16x2', action='store_true',
+                    help='f16x2 mode: the one-launch training forward on the t4 kernel (off by default: slower end to end)')
     args = ap.parse_args()
+    from normalizing_flows_amd import transforms as _tr
+    if args.two_launch_forward:
+        _tr.FUSED_TRAINING_FORWARD = False
+    if args.fused_forward_f16x2:
+        _tr.FUSED_TRAINING_FORWARD_F16X2 = True
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))

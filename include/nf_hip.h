@@ -171,7 +171,10 @@ int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void* packed_w, 
 /* nf_made_rqs_fwd (forward direction, NF_DTYPE_F32 / NF_DTYPE_BF16) that also KEEPS the conditioner output: params_out
  * [B, features * P] as nf_masked_linear_fwd would have written it (made.py:358), logits unfolded with `logit_div` (the
  * value given to nf_made_rqs_pack_scaled, 1 for nf_made_rqs_pack).  The training forward: nf_rqs_bwd recomputes from
- * (x, params), and the parameters are not read back between the GEMM and the spline. */
+ * (x, params), and the parameters are not read back between the GEMM and the spline.  NF_DTYPE_F16X2 (round 3): the
+ * same on the f16x2 "t4" kernel - whole layers only, with the workspace of nf_made_rqs_workspace_bytes_dtype (logdet
+ * partials + scale slot + term planes), else NF_ERR_SCRATCH and the caller runs nf_masked_linear_split_fwd + nf_rqs_fwd. */
+int nf_made_rqs_fwd_params_supported(int K, int tails, int dtype);   /* 1: nf_made_rqs_fwd_params takes such packs */
 int nf_made_rqs_fwd_params(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
                            const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
                            int64_t y_row_stride, float* logabsdet, int accumulate, float* workspace,

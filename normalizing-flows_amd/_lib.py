@@ -190,6 +190,7 @@ _SIGNATURES = {
                                           _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_double,
                                           _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_double, _c.c_void_p,
                                           _c.c_int64, _c.c_void_p]),
+    'nf_made_rqs_fwd_params_supported': (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     'nf_made_rqs_fwd_params_bf16': (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                                _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p,
                                                _c.c_size_t, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
@@ -927,8 +928,15 @@ def made_rqs_planes(planes, row_scale, pf, x, tail_bound, inverse=False, out=Non
 
 
 def made_rqs_keeps_params(pf):
-    """Can the fused launch also write the conditioner output (nf_made_rqs_fwd_params)?  The f32 / bf16 kernel only."""
-    return pf.dtype in (NF_DTYPE_F32, NF_DTYPE_BF16)
+    """Can the fused launch also write the conditioner output (nf_made_rqs_fwd_params)?  The f32 / bf16 kernel, and the
+    f16x2 t4 kernel where its stages fit LDS."""
+    return made_rqs_params_supported(pf.K, 'linear' if pf.tails else None, pf.dtype)
+
+
+def made_rqs_params_supported(num_bins, tails, dtype):
+    """Does the kept-parameters training forward (made_rqs_params) exist for this spline shape and pack dtype?"""
+    return tails in (None, 'linear') and \
+        load().nf_made_rqs_fwd_params_supported(int(num_bins), 1 if tails == 'linear' else 0, int(dtype)) == 1
 
 
 def made_rqs_params(h, pf, x, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, logit_div=1.0,
@@ -950,7 +958,7 @@ def made_rqs_params(h, pf, x, tail_bound, min_bin_width=1e-3, min_bin_height=1e-
     yp, ys = _rows(out, 'outputs')
     logabsdet = torch.empty(B, dtype=torch.float32, device=x.device)
     params = torch.empty((B, pf.features * P), dtype=torch.bfloat16 if keep_bf16 else torch.float32, device=x.device)
-    ws = fused_workspace(pf, B, x.device, planes=False)
+    ws = fused_workspace(pf, B, x.device, planes=pf.dtype == NF_DTYPE_F16X2)     # (f16x2: the t4 kernel reads planes)
     y_max = torch.empty(1, dtype=torch.int32, device=x.device) if keep_bf16 else None
 
     def launch():

@@ -2335,9 +2335,18 @@ __global__ __launch_bounds__(256 * RT, 2) void made_rqs_f16x2_t_kernel(const Fus
     const int fl = RT == 2 ? w >> 1 : w;                                     // wave-uniform feature slot
     const int r0 = (RT == 2 ? (w & 1) * 128 : 0) + lane, r1 = r0 + 64;       // this lane's two sample rows
     float lsum0 = 0.f, lsum1 = 0.f;
+    // kept parameters: columns lane and lane + 64 of a pass (YFP * P <= 128 of them), 1 or the un-fold factor
+    float keep_scale[2] = {1.f, 1.f};
+    if (g.params_out) {
+        keep_scale[0] = (lane % P) < 2 * g.c.K ? g.unfold : 1.f;
+        keep_scale[1] = ((lane + 64) % P) < 2 * g.c.K ? g.unfold : 1.f;
+    }
 #pragma unroll 1
     for (int f_pass = 0; f_pass < fv; f_pass += YFP) {
         const int c0 = f_pass * P, c1 = min(f_pass + YFP, fpt) * P;
+        // (kept parameters: LDS-only barriers - __syncthreads() also drains vmcnt, i.e. would wait out the previous
+        //  pass's parameter stores, a write latency per pass with nothing else to run)
+        if (g.params_out) lds_only_barrier(); else
         __syncthreads();                                     // stages / previous pass fully consumed
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -2357,7 +2366,23 @@ __global__ __launch_bounds__(256 * RT, 2) void made_rqs_f16x2_t_kernel(const Fus
                 }
             }
         }
+        if (g.params_out) lds_only_barrier(); else
         __syncthreads();
+        if (g.params_out) {
+            // training forward (nf_made_rqs_fwd_params, f16x2 packs): the pass's parameters - whole features, c1 - c0
+            // consecutive floats per row - leave as they lie in the tile, a wave per row and lanes along the row
+            // (coalesced runs of up to 256 bytes), the logit columns un-folded (the pack multiplied them by log2(e) /
+            // logit_div).  Issued in front of the evaluation, which does not wait for them.
+            const int nc = min(c1, fv * P) - c0;
+            for (int rr = w; rr < ROWS; rr += NW) {
+                const int64_t row = m0 + rr;
+                if (row < g.M) {
+                    float* po = g.params_out + row * g.ldp + (int64_t)(f0 + f_pass) * P;
+                    if (lane < nc) po[lane] = tile[lane * LDTR + rr] * keep_scale[0];
+                    if (lane + 64 < nc) po[lane + 64] = tile[(lane + 64) * LDTR + rr] * keep_scale[1];
+                }
+            }
+        }
         const int f = f_pass + fl;
 #if NF_EPI_PRIO
         __builtin_amdgcn_s_setprio(NF_EPI_PRIO);             // the evaluation's VALU stream ahead of the partner workgroup's issue
@@ -2712,9 +2737,10 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
         h = (const float*)planes_in;                 // (only so that the null / alignment checks below pass: never read)
         h_row_stride = (in + 3) / 4 * 4;
     }
-    if (params_out && (split_terms(dtype) || inverse || feat_index ||
+    if (params_out && ((split_terms(dtype) && (dtype != NF_DTYPE_F16X2 || params_bf16)) || inverse || feat_index ||
                        params_row_stride < (int64_t)features * (tails ? 3 * K - 1 : 3 * K + 1)))
-        return NF_ERR_LAYOUT;                       // (the f32 / bf16 forward kernel of whole autoregressive layers)
+        return NF_ERR_LAYOUT;                       // (the f32 / bf16 forward kernel of whole autoregressive layers, or
+                                                    //  the f16x2 t4 kernel with the planes in the workspace - below)
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_ERR_BINS;
     if (dtype != NF_DTYPE_F32 && dtype != NF_DTYPE_BF16 && !split_terms(dtype)) return NF_ERR_DTYPE;
     if (y_max) {
@@ -2778,6 +2804,23 @@ static int fused_fwd_impl(const float* h, int64_t h_row_stride, const void* pack
                 g.hp = (const char*)workspace + part + 256;
                 g.hp_ld = kp16_of(in);
             }
+            if (params_out) {
+                // the kept-parameters forward exists in the t4 kernel only: whole layer, planes in the workspace
+                // (nf_made_rqs_workspace_bytes_dtype), ring within LDS - else the caller's two-launch route
+                if (!pre || feat_limit != features || w8_ring_bytes(g.c.P) + w8_xs_bytes(g.fpt) > 160 * 1024)
+                    return NF_ERR_SCRATCH;
+                if (!h_max) {
+                    const int rm = maxabs_rows(h, h_row_stride, B, in, const_cast<unsigned*>(g.hmax), s);
+                    if (rm != NF_OK) return rm;
+                }
+                const int ksteps = (int)(g.hp_ld / XS);
+                const int64_t chunks = (B + YM - 1) / YM * YM * ksteps * 2;
+                const int sgrid = (int)((chunks + 255) / 256 < 65536 ? (chunks + 255) / 256 : 65536);
+                hipLaunchKernelGGL(split_planes_tiled_kernel<SplitF16x2>, dim3(sgrid), dim3(256), 0, s, h, h_row_stride, B,
+                                   in, ksteps, g.hmax, (_Float16*)g.hp);
+                const size_t lds8 = (size_t)w8_ring_bytes(g.c.P, 1) + w8_xs_bytes(g.fpt, 1);
+                rc = launch_k_t<false, 1>(g, (int)grid, lds8, s);
+            } else
             rc = dtype == NF_DTYPE_BF16X3 ? run_split<SplitBf16x3>(g, (int)grid, lds, pre, h_max == nullptr, h, h_row_stride, B, in, inverse, s)
                                           : run_split<SplitF16x2>(g, (int)grid, lds, pre, h_max == nullptr, h, h_row_stride, B, in, inverse, s);
         }
@@ -2864,7 +2907,18 @@ extern "C" int nf_made_rqs_fwd(const float* h, int64_t h_row_stride, const void*
 // nf_made_rqs_fwd that also KEEPS the conditioner output: params[B, features * P] as nf_masked_linear_fwd would have
 // written it (logits unfolded with `logit_div`, the value given to nf_made_rqs_pack_scaled; 1 for nf_made_rqs_pack).
 // The training forward: one launch instead of GEMM + spline kernel, and `params` is not read back in between.
-// NF_DTYPE_F32 / NF_DTYPE_BF16, forward direction.
+// NF_DTYPE_F32 / NF_DTYPE_BF16, forward direction; NF_DTYPE_F16X2 (round 3) on the t4 kernel, which needs the workspace
+// of nf_made_rqs_workspace_bytes_dtype (logdet partials + scale slot + term planes; NF_ERR_SCRATCH otherwise).
+// Does nf_made_rqs_fwd_params take packs of this dtype for this spline shape?  (f16x2: the t4 kernel's ring of stages
+// and its parameter tile must fit LDS.)
+extern "C" int nf_made_rqs_fwd_params_supported(int K, int tails, int dtype) {
+    if (!fused_supported(K, tails)) return 0;
+    if (dtype == NF_DTYPE_F32 || dtype == NF_DTYPE_BF16) return 1;
+    if (dtype != NF_DTYPE_F16X2) return 0;
+    const int P = tails ? 3 * K - 1 : 3 * K + 1;
+    return w8_ring_bytes(P) + w8_xs_bytes(fpt_of(P)) <= 160 * 1024 ? 1 : 0;
+}
+
 extern "C" int nf_made_rqs_fwd_params(const float* h, int64_t h_row_stride, const void* packed_w, const int32_t* ktab,
                                       const float* bias_packed, const float* x, int64_t x_row_stride, float* y,
                                       int64_t y_row_stride, float* logabsdet, int accumulate, float* workspace,

@@ -34,6 +34,13 @@ ROW_RESIDENT_INVERSE = True
 FUSED_HIDDEN_STACK = True
 # False: RQ coupling layers run as hidden-stack launch + fused final layer launch (A/B measurements, tests of that path)
 FUSED_COUPLING_LAYER = True
+# training forward of an autoregressive RQ layer as one launch that keeps the conditioner output (False: GEMM + spline
+# as two autograd nodes; A/B and tests)
+FUSED_TRAINING_FORWARD = True
+# ... in the f16x2 mode too (the t4 kernel storing its parameter tile).  Off: measured on one box, B = 32768, the launch
+# takes 1.995 ms against 1.50 + 0.56 ms for GEMM + spline kernel, but the plane split, the hidden-state max pass and the
+# pack's table scan around it make the step 0.8 ms (2 %) SLOWER than the two-node graph.
+FUSED_TRAINING_FORWARD_F16X2 = False
 
 
 def _check_2d(inputs, features):
@@ -293,7 +300,10 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         parameter tensor is materialised here (the backward needs it); inference uses the fused kernel."""
         net = self.autoregressive_net
         inputs = inputs.contiguous()
-        if self._fusable() and made_module.get_matmul_dtype() in ('f32', 'bf16'):
+        mode = made_module.get_matmul_dtype()
+        if self._fusable() and FUSED_TRAINING_FORWARD and \
+                (mode in ('f32', 'bf16') or (mode == 'f16x2' and FUSED_TRAINING_FORWARD_F16X2)) and \
+                _lib.made_rqs_params_supported(self.num_bins, self.tails, made_module._MATMUL_DTYPE[mode]):
             # one launch for the final layer and the spline that also writes the parameters its backward recomputes
             # from (nf_made_rqs_fwd_params): they are not read back between the GEMM and the spline
             from .autograd import FinalRqsFn

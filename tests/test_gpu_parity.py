@@ -2722,6 +2722,86 @@ def test_fused_training_forward_leaves_the_largest_output(nf):
     assert _lib.tagged_max(y32) is None
 
 
+@pytest.mark.parametrize('B', [777, 130])
+def test_f16x2_fused_training_forward_keeps_the_parameters(nf, B):
+    """nf_made_rqs_fwd_params on an f16x2 pack (the t4 kernel storing the conditioner output from its parameter tile):
+    y / logabsdet equal the inference launch of the same kernel bit for bit, the kept parameters are the final layer's
+    output (made.py:358) to the fp32 contract - logit columns un-folded -, ragged batches included."""
+    from normalizing_flows_amd import _lib
+    D, H, K, Tb = 30, 136, 8, 3.0
+    P = 3 * K - 1
+    assert _lib.made_rqs_params_supported(K, 'linear', _lib.NF_DTYPE_F16X2)
+    sd = O.seeded_made_state_dict(D, H, P, seed=33, scale=0.1)
+    w, m, b = (sd['autoregressive_net.final_layer.' + k].cuda() for k in ('weight', 'mask', 'bias'))
+    pf = _lib.PackedFusedFinal(w, m, b, D, K, 'linear', _lib.NF_DTYPE_F16X2)
+    g = torch.Generator().manual_seed(B)
+    h = torch.randn(B, H, generator=g).relu().cuda()
+    x = (torch.randn(B, D, generator=g) * 1.5).cuda()
+    import os
+    old = os.environ.get('NF_FUSED_F16X2_KERNEL')
+    os.environ['NF_FUSED_F16X2_KERNEL'] = 't4'
+    try:
+        y0, l0, _ = _lib.made_rqs(h, pf, x, Tb)
+    finally:
+        if old is None:
+            os.environ.pop('NF_FUSED_F16X2_KERNEL', None)
+        else:
+            os.environ['NF_FUSED_F16X2_KERNEL'] = old
+    y1, l1, params = _lib.made_rqs_params(h, pf, x, Tb)
+    assert params.dtype == torch.float32 and params.shape == (B, D * P)
+    assert torch.equal(y1, y0) and torch.equal(l1, l0)
+    p64 = h.cpu().double() @ (w * m).cpu().double().t() + b.cpu().double()
+    p32 = h.cpu() @ (w * m).cpu().t() + b.cpu()
+    assert_close(params, p64, p32)
+    # the spline backward recomputes from the kept parameters: they must reproduce y through the standalone kernel
+    y2, l2, _ = _lib.rqs(x, params, K, 'linear', Tb)
+    assert (y2 - y1).abs().max().item() < 2e-5 and (l2 - l1).abs().max().item() < 2e-4 * max(1.0, l1.abs().max().item())
+
+
+def test_f16x2_training_step_with_and_without_the_fused_forward(nf):
+    """f16x2 training mode: FinalRqsFn on the t4 kernel (one launch, parameters kept) against the two-node graph
+    (split-operand GEMM + spline kernel): loss and gradients agree to the accumulation order of the two GEMM kernels."""
+    from importlib import import_module
+    tr = import_module(nf.__name__ + '.transforms')
+    D, H, K, B, Tb = 24, 64, 8, 300, 3.0
+    sds = [O.seeded_made_state_dict(D, H, 3 * K - 1, seed=70 + j, scale=0.1) for j in range(2)]
+    x = (torch.randn(B, D, generator=torch.Generator().manual_seed(10)) * 1.2).cuda()
+    nf.set_matmul_dtype('f16x2')
+    res = {}
+    try:
+        for fused in (True, False):
+            tr.FUSED_TRAINING_FORWARD_F16X2 = fused     # (off by default: measured 2 % slower end to end, DESIGN)
+            flow = nf.BaseNeuralSplineFlow(nf.CompositeTransform(_load_layers(nf, sds, D, H, K, Tb)),
+                                           nf.StandardNormal([D])).cuda().train()
+            lp = flow.log_prob(x)
+            names, fn, seen = set(), [lp.grad_fn], set()
+            while fn:
+                f = fn.pop()
+                if f is None or f in seen:
+                    continue
+                seen.add(f)
+                names.add(type(f).__name__)
+                fn.extend(n for n, _ in f.next_functions)
+            assert any('FinalRqsFn' in n for n in names) == fused
+            (-lp.mean()).backward()
+            res[fused] = (lp.detach(), {k: p.grad.clone() for k, p in flow.named_parameters()})
+    finally:
+        tr.FUSED_TRAINING_FORWARD_F16X2 = False
+        nf.set_matmul_dtype('f32')
+    assert (res[True][0] - res[False][0]).abs().max().item() <= 1e-5 * res[False][0].abs().max().item()
+    for k, gf in res[True][1].items():
+        g2 = res[False][1][k]
+        assert (gf - g2).abs().max().item() <= 2e-4 * (g2.abs().max().item() + 1e-20), k
+    tr.FUSED_TRAINING_FORWARD_F16X2 = True
+    nf.set_matmul_dtype('f16x2')
+    try:                                               # the fused forward against the fp64 oracle's gradients
+        test_training_gradients_match_autograd_of_the_oracle(nf, 40, 136, 4, 130)
+        test_training_gradients_match_autograd_of_the_oracle(nf, 16, 32, 8, 96)
+    finally:
+        tr.FUSED_TRAINING_FORWARD_F16X2 = False
+        nf.set_matmul_dtype('f32')
+
+
 @pytest.mark.parametrize('mode', ['f32', 'f16x2', 'bf16'])
 def test_residual_block_as_one_autograd_node(nf, mode):
     """autograd.ResidualBlockFn (one node per plain residual block; the skip gradient joins the first layer's
