@@ -73,18 +73,36 @@ __global__ __launch_bounds__(256) void hs_scan_kernel(const float* __restrict__ 
                                                       int out, int in, HiddenHdr* hdr, int layer) {
     float mx = 0.f;
     const int64_t total = (int64_t)out * in;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int u = (int)(i / in), k = (int)(i - (int64_t)u * in);
-        const float m = mask ? mask[i] : 1.f;
+    const int lane = threadIdx.x & 63;
+    // a wave takes 64 consecutive elements - as a rule one weight row, so one 32-unit group: its largest live K step
+    // goes out as ONE atomic (one per unmasked element was a quarter of a million atomics on 16 addresses, all in
+    // flight at once: 1.2 ms per layer).  The loop is wave-uniform so that the shuffles see every lane.
+    const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(int64_t)63;
+    for (int64_t base = w0; base < total; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + lane;
+        const bool valid = i < total;
+        const int64_t ic = valid ? i : total - 1;
+        const int u = (int)(ic / in), k = (int)(ic - (int64_t)u * in);
+        const float m = !valid ? 0.f : (mask ? mask[ic] : 1.f);
+        int ks = 0;
         if (m != 0.f) {
-            const float a = fabsf(W[i] * m);
+            const float a = fabsf(W[ic] * m);
             if (a < INFINITY) mx = fmaxf(mx, a);
-            atomicMax(&hdr->layer[layer].kend[u >> 5], k / 16 + 1);
+            ks = k / 16 + 1;
+        }
+        const int grp = u >> 5;
+        const int g0 = __builtin_amdgcn_readfirstlane(grp);
+        if (__all(grp == g0)) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ks = max(ks, __shfl_xor(ks, off, 64));
+            if (lane == 0 && ks > 0) atomicMax(&hdr->layer[layer].kend[g0], ks);
+        } else if (ks > 0) {
+            atomicMax(&hdr->layer[layer].kend[grp], ks);
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&hdr->layer[layer].wmax, __float_as_uint(mx));
+    if (lane == 0 && mx > 0.f) atomicMax(&hdr->layer[layer].wmax, __float_as_uint(mx));
 }
 
 // weights of one layer in MFMA A-operand order: [group][K step][term][lane][8 halfs], lane l = unit 32 g + l % 32,
