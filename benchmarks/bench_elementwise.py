@@ -88,6 +88,12 @@ def main():
     p = torch.randn(B, D * (2 * K + 2), device='cuda', generator=g)
     report_bwd('cubic_spline_bwd_K8', 2 * K + 2, lambda: _lib.family_spline_bwd('cubic', x, p, gy, gl, K, tails='linear',
                                                                                 tail_bound=10.0))
+    del p
+    p = torch.randn(B, D * K, device='cuda', generator=g)
+    report_bwd('linear_spline_bwd_K8', K, lambda: _lib.family_spline_bwd('linear', u, p, gy, gl, K))
+    del p
+    p = torch.randn(B, D * (2 * K + 1), device='cuda', generator=g)
+    report_bwd('quadratic_spline_bwd_K8', 2 * K + 1, lambda: _lib.family_spline_bwd('quadratic', u, p, gy, gl, K))
     print(json.dumps(out))
 
 

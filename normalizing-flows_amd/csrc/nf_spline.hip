@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
     const int nrows = (int)min((int64_t)a.rows_per_block, a.B - row0);
     const int E = nrows * D;
     float* stage = smem;
-    constexpr bool kInPlace = FAM == 0 || (FAM == 3 && KT > 0);      // the evaluator overwrites the staged parameters
+    constexpr bool kInPlace = FAM == 0 || KT > 0;                    // the evaluator overwrites the staged parameters
     float* gout = kInPlace ? smem : smem + ((kThreads * P + 4 + 3) & ~3);
     const int64_t e0 = row0 * D;
     const int64_t gblk = e0 * P;
@@ -362,9 +362,13 @@ __global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
             float* ps = stage + st.shift + tid * P;
             float* gs = gout + st.shift + tid * P;
             float gxv;
-            if (FAM == 1) gxv = lin_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
-            else if (FAM == 2) gxv = quad_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
-            else if (FAM == 3) {
+            if (FAM == 1) {
+                if constexpr (KT > 0) gxv = lin_bwd_eval_t<KT>(ps, xv, gyv, gl, a.c, a.inverse != 0);
+                else gxv = lin_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
+            } else if (FAM == 2) {
+                if constexpr (KT > 0) gxv = quad_bwd_eval_t<KT>(ps, xv, gyv, gl, a.c, a.inverse != 0);
+                else gxv = quad_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
+            } else if (FAM == 3) {
                 if constexpr (KT > 0) gxv = cubic_bwd_eval_t<KT>(ps, xv, gyv, gl, a.c, a.inverse != 0);
                 else gxv = cubic_bwd_eval(ps, gs, xv, gyv, gl, a.c, a.inverse != 0);
             }
@@ -449,13 +453,11 @@ template <int FAM>
 int launch_family_bwd(const RqsBwdArgs& a, int grid, size_t lds, hipStream_t s) {
     const int nv = (kThreads * a.c.P + 4 + 3) / 4;
     const int per = (nv + kThreads - 1) / kThreads;
-    if constexpr (FAM == 3) {
-        if ((a.c.K == 8 || a.c.K == 10) && per <= 6) {            // bin count as a template constant, gradients in place
-            const size_t lds1 = lds / 2;
-            if (a.c.K == 8) hipLaunchKernelGGL((rqs_bwd_kernel<8, 6, 3>), dim3(grid), dim3(kThreads), lds1, s, a);
-            else hipLaunchKernelGGL((rqs_bwd_kernel<10, 6, 3>), dim3(grid), dim3(kThreads), lds1, s, a);
-            return nf_launch_status();
-        }
+    if ((a.c.K == 8 || a.c.K == 10) && per <= 6) {                // bin count as a template constant, gradients in place
+        const size_t lds1 = lds / 2;
+        if (a.c.K == 8) hipLaunchKernelGGL((rqs_bwd_kernel<8, 6, FAM>), dim3(grid), dim3(kThreads), lds1, s, a);
+        else hipLaunchKernelGGL((rqs_bwd_kernel<10, 6, FAM>), dim3(grid), dim3(kThreads), lds1, s, a);
+        return nf_launch_status();
     }
     static unsigned long long raised[3] = {0, 0, 0};
 #define NF_FAM_BWD(MAXV)                                                                              \

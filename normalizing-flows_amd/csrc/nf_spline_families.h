@@ -881,3 +881,208 @@ __device__ __forceinline__ float cubic_bwd_eval_t(float* p, float x, float gy, f
     return ret;
 }
 
+// Linear and quadratic reverse sweeps with the bin count as a template constant, on the same scheme as cubic_bwd_eval_t:
+// the element's parameters move to registers once, every index is static after unrolling, quotients share one refined
+// reciprocal per denominator (nf_div_ieee), the gradients are written over the parameters in place.  Same formulas in
+// the same order as lin_bwd_eval / quad_bwd_eval; the softmax values are kept (those re-derive them from the widths).
+template <int KT>
+__device__ __forceinline__ float lin_bwd_eval_t(float* p, float x, float gy, float gl, const RqsConst& a, bool inv) {
+    constexpr int K = KT;
+    typedef __attribute__((address_space(3))) float* lds_w;
+    lds_w pl = (lds_w)p;
+    if (a.tails && !(x >= a.left && x <= a.right)) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) pl[k] = 0.0f;
+        return gy;
+    }
+    float e[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) e[k] = pl[k];
+    const float t = nf_div_ieee(x - a.left, nf_divisor(a.span));
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) m = fmaxf(m, e[k]);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        e[k] = nf_exp(e[k] - m);
+        s += e[k];
+    }
+    const NfDivisor ds = nf_divisor(s);
+    const float pos = t * (float)K;
+    int b = (int)floorf(pos);
+    b = b >= K ? K - 1 : (b < 0 ? 0 : b);
+    const float alpha = pos - (float)b;
+    float cb = 0.0f, pb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        e[k] = nf_div_ieee(e[k], ds);                     // the normalised pdf
+        cb += k < b ? e[k] : 0.0f;
+        pb = k == b ? e[k] : pb;
+    }
+    const float o = cb + alpha * pb;
+    const float fp = (float)K * pb;
+    float A = 0.0f;
+    if (inv) {
+        A = gy / fp;
+        gy = -A;
+        gl = -gl;
+    } else if (!(o >= 0.0f && o <= 1.0f)) {
+        gy = 0.0f;
+    }
+    const float go = gy * a.span;
+    const float S = go * o + gl;
+    const float gpb = go * alpha + gl / pb;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float gp = k < b ? go : (k == b ? gpb : 0.0f);
+        pl[k] = e[k] * (gp - S);
+    }
+    return inv ? A : gy * fp;
+}
+
+template <int KT>
+__device__ __forceinline__ float quad_bwd_eval_t(float* p, float x, float gy, float gl, const RqsConst& a, bool inv) {
+    constexpr int K = KT;
+    typedef __attribute__((address_space(3))) float* lds_w;
+    lds_w pl = (lds_w)p;
+    const int P = a.P;
+    if (a.tails && !(x >= a.left && x <= a.right)) {
+        for (int k = 0; k < P; ++k) pl[k] = 0.0f;
+        return gy;
+    }
+    const bool tails = a.tails != 0;
+    float wv[K], sm[K], ev[K + 1];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wv[k] = pl[k];
+#pragma unroll
+    for (int j = 0; j < K + 1; ++j) ev[j] = (j < K - 1 || !tails) ? nf_exp(pl[K + j]) : 0.0f;     // K - 1 or K + 1 heights
+    const float t = nf_div_ieee(x - a.left, nf_divisor(a.span));
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) m = fmaxf(m, wv[k]);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        wv[k] = nf_exp(wv[k] - m);
+        s += wv[k];
+    }
+    const NfDivisor ds = nf_divisor(s);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        sm[k] = nf_div_ieee(wv[k], ds);
+        wv[k] = a.min_w + a.scale_w * sm[k];
+    }
+    float cst = 0.0f, num = 0.0f, den = 1.0f;
+    if (tails) {
+        const float first = 0.5f * wv[0], last = 0.5f * wv[K - 1];
+        float mid = 0.0f;
+#pragma unroll
+        for (int j = 0; j + 1 < K - 1; ++j) mid += ((ev[j] + ev[j + 1]) / 2.0f) * wv[j + 1];
+        num = 0.5f * first * ev[0] + 0.5f * last * ev[K - 2] + mid;
+        den = 1.0f - 0.5f * first - 0.5f * last;
+        cst = num / den;
+    }
+    float Hk[K + 1];                                     // unnormalised knot heights
+#pragma unroll
+    for (int k = 0; k <= K; ++k) Hk[k] = !tails ? ev[k] : ((k == 0 || k == K) ? cst : ev[k > 0 ? k - 1 : 0]);
+    float area = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) area += ((Hk[k] + Hk[k + 1]) / 2.0f) * wv[k];
+    const float omh = 1.0f - a.min_h;
+    const NfDivisor da = nf_divisor(area);
+    float hg[K + 1];                                     // normalised knot heights
+#pragma unroll
+    for (int k = 0; k <= K; ++k) hg[k] = a.min_h + omh * nf_div_ieee(Hk[k], da);
+    double accw = 0.0, accc = 0.0;
+    float loc0 = 0.0f, cdf0 = 0.0f, loc = 0.0f, w = 1.0f, c = 0.0f, hl = 1.0f, hr = 1.0f;
+    int b = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        accw += (double)wv[k];
+        accc += (double)(((hg[k] + hg[k + 1]) / 2.0f) * wv[k]);
+        if (t >= loc0) { b = k; loc = loc0; w = wv[k]; c = cdf0; hl = hg[k]; hr = hg[k + 1]; }
+        loc0 = (float)accw;
+        cdf0 = (float)accc;
+    }
+    const NfDivisor dw = nf_divisor(w);
+    const float alpha = nf_div_ieee(t - loc, dw);
+    const float dens = alpha * (hr - hl) + hl;
+    const float o = (0.5f * (hr - hl) * w) * (alpha * alpha) + (hl * w) * alpha + c;
+    const float fp = dens;
+    const NfDivisor dd = nf_divisor(dens);
+    const float dldx = nf_div_ieee(nf_div_ieee(hr - hl, nf_divisor(dens * w)), nf_divisor(a.span));
+    float A = 0.0f;
+    if (inv) {
+        A = nf_div_ieee(gy - gl * dldx, dd);
+        gy = -A;
+        gl = -gl;
+    } else if (!(o >= 0.0f && o <= 1.0f)) {
+        gy = 0.0f;
+    }
+    const float go = gy * a.span;
+    const float ga = go * w * dens + nf_div_ieee(gl * (hr - hl), dd);
+    const float gloc = -nf_div_ieee(ga, dw);
+    const float gwd = go * (0.5f * (hr - hl) * (alpha * alpha) + hl * alpha) - nf_div_ieee(ga * alpha, dw);
+    const float ghl = go * w * (alpha - 0.5f * (alpha * alpha)) + nf_div_ieee(gl * (1.0f - alpha), dd);
+    const float ghr = go * 0.5f * w * (alpha * alpha) + nf_div_ieee(gl * alpha, dd);
+    const float gc = go;
+    float gh[K + 1];                                     // dL/d (normalised knot height k)
+    float sgh = 0.0f;
+#pragma unroll
+    for (int k = 0; k <= K; ++k) {
+        float v = 0.0f;
+        if (k >= 1) v += (k - 1 < b) ? gc * 0.5f * wv[k - 1] : 0.0f;
+        if (k < K) v += (k < b) ? gc * 0.5f * wv[k] : 0.0f;
+        v += (k == b) ? ghl : 0.0f;
+        v += (k == b + 1) ? ghr : 0.0f;
+        gh[k] = v;
+        sgh += v * Hk[k];
+    }
+    const float garea = -nf_div_ieee(omh, nf_divisor(area * area)) * sgh;
+    float gE[K + 1], gw[K];
+    float gcst = 0.0f;
+#pragma unroll
+    for (int k = 0; k <= K; ++k) {
+        const float wl = k >= 1 ? wv[k - 1] : 0.0f, wr = k < K ? wv[k] : 0.0f;
+        const float v = nf_div_ieee(omh * gh[k], da) + garea * 0.5f * (wl + wr);
+        if (!tails) gE[k] = v;
+        else if (k == 0 || k == K) gcst += v;
+        else gE[k - 1] = v;
+    }
+    if (tails) gE[K - 1] = gE[K] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float v = garea * 0.5f * (Hk[k] + Hk[k + 1]);
+        v += (k < b) ? gloc + gc * 0.5f * (hg[k] + hg[k + 1]) : 0.0f;
+        v += (k == b) ? gwd : 0.0f;
+        gw[k] = v;
+    }
+    if (tails) {
+        const float gnum = gcst / den;
+        const float gden = -gcst * num / (den * den);
+        gw[0] += -0.25f * gden + 0.25f * ev[0] * gnum;
+        gw[K - 1] += -0.25f * gden + 0.25f * ev[K - 2] * gnum;
+        gE[0] += 0.25f * wv[0] * gnum;
+        gE[K - 2] += 0.25f * wv[K - 1] * gnum;
+#pragma unroll
+        for (int j = 0; j + 1 < K - 1; ++j) {
+            const float wj = wv[j + 1];
+            gE[j] += gnum * 0.5f * wj;
+            gE[j + 1] += gnum * 0.5f * wj;
+            gw[j + 1] += gnum * 0.5f * (ev[j] + ev[j + 1]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j <= K; ++j) gE[j] *= ev[j];
+    float S = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) S += a.scale_w * gw[k] * sm[k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) pl[k] = sm[k] * (a.scale_w * gw[k] - S);
+#pragma unroll
+    for (int j = 0; j <= K; ++j)
+        if (j < K - 1 || !tails) pl[K + j] = gE[j];
+    return inv ? A : gy * fp + gl * dldx;
+}
+

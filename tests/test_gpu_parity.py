@@ -2253,12 +2253,14 @@ def test_spline_family_backward_kernels(nf, family, direction):
     _check_family_backward(nf, family, direction, 6)
 
 
-@pytest.mark.parametrize('family', ['cubic', 'cubic_tails_prediv'])
+@pytest.mark.parametrize('family', ['cubic', 'cubic_tails_prediv', 'linear', 'linear_tails', 'quadratic',
+                                    'quadratic_tails'])
 @pytest.mark.parametrize('direction', ['fwd', 'inv'])
 @pytest.mark.parametrize('K', [8, 10])
-def test_cubic_backward_kernel_with_template_bin_counts(nf, family, direction, K):
-    """K = 8 / 10 take the cubic reverse sweep with the bin count as a template constant (parameters in registers,
-    gradients written over the staged parameters in place): the same bars as the runtime-K kernel above."""
+def test_family_backward_kernels_with_template_bin_counts(nf, family, direction, K):
+    """K = 8 / 10 take the linear / quadratic / cubic reverse sweeps with the bin count as a template constant
+    (parameters in registers, gradients written over the staged parameters in place): the same bars as the runtime-K
+    kernels above."""
     _check_family_backward(nf, family, direction, K)
 
 
