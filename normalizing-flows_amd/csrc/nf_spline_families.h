@@ -952,7 +952,7 @@ __device__ __forceinline__ float quad_bwd_eval_t(float* p, float x, float gy, fl
         return gy;
     }
     const bool tails = a.tails != 0;
-    float wv[K], sm[K], ev[K + 1];
+    float wv[K], ev[K + 1];
 #pragma unroll
     for (int k = 0; k < K; ++k) wv[k] = pl[k];
 #pragma unroll
@@ -969,10 +969,7 @@ __device__ __forceinline__ float quad_bwd_eval_t(float* p, float x, float gy, fl
     }
     const NfDivisor ds = nf_divisor(s);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        sm[k] = nf_div_ieee(wv[k], ds);
-        wv[k] = a.min_w + a.scale_w * sm[k];
-    }
+    for (int k = 0; k < K; ++k) wv[k] = a.min_w + a.scale_w * nf_div_ieee(wv[k], ds);
     float cst = 0.0f, num = 0.0f, den = 1.0f;
     if (tails) {
         const float first = 0.5f * wv[0], last = 0.5f * wv[K - 1];
@@ -1040,7 +1037,8 @@ __device__ __forceinline__ float quad_bwd_eval_t(float* p, float x, float gy, fl
         sgh += v * Hk[k];
     }
     const float garea = -nf_div_ieee(omh, nf_divisor(area * area)) * sgh;
-    float gE[K + 1], gw[K];
+    float gw[K];
+    float (&gE)[K + 1] = gh;                             // the slot of knot k is free once its own value is taken
     float gcst = 0.0f;
 #pragma unroll
     for (int k = 0; k <= K; ++k) {
@@ -1075,11 +1073,16 @@ __device__ __forceinline__ float quad_bwd_eval_t(float* p, float x, float gy, fl
     }
 #pragma unroll
     for (int j = 0; j <= K; ++j) gE[j] *= ev[j];
+    // (the softmax values back from the widths, as quad_bwd_eval has them: eight registers less across the sweep)
+    const float isw = 1.0f / a.scale_w;
     float S = 0.0f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) S += a.scale_w * gw[k] * sm[k];
+    for (int k = 0; k < K; ++k) {
+        wv[k] = (wv[k] - a.min_w) * isw;
+        S += a.scale_w * gw[k] * wv[k];
+    }
 #pragma unroll
-    for (int k = 0; k < K; ++k) pl[k] = sm[k] * (a.scale_w * gw[k] - S);
+    for (int k = 0; k < K; ++k) pl[k] = wv[k] * (a.scale_w * gw[k] - S);
 #pragma unroll
     for (int j = 0; j <= K; ++j)
         if (j < K - 1 || !tails) pl[K + j] = gE[j];
