@@ -288,8 +288,9 @@ struct RqsBwdArgs {
 // FAM 0: rational-quadratic (gradients overwrite the staged parameters in place); 1 / 2 / 3: linear / quadratic /
 // cubic family (nf_spline_families.h), whose reverse sweeps keep the parameters and write a second LDS region.
 // The next span's parameters are in flight (registers) while this one is evaluated and written back.
+// (bf16-parameter flavour: 136 registers uncapped = three waves per SIMD; it fits 128 without a spill = four)
 template <int KT, int MAXV, int FAM = 0, bool PB16 = false>
-__global__ __launch_bounds__(kThreads) void rqs_bwd_kernel(const RqsBwdArgs a) {
+__global__ __launch_bounds__(kThreads, (FAM == 0 && PB16) ? 4 : 1) void rqs_bwd_kernel(const RqsBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int P = a.c.P;
